@@ -1,0 +1,341 @@
+/*
+ * pbrt_hip.h -- C-ABI of libpbrt_hip.so, the MI355X (gfx950) Monte-Carlo ray-transport engine.
+ *
+ * This is the drop-in boundary of the hot path.  The reference
+ * (ReaganCardoza/Physics-Based-Ray-Tracing) has NO FFI: its boundary is the Mitsuba-3 Python
+ * plugin API.  Each entry point below therefore cites the reference *Python* interface it
+ * replaces (file:line relative to the reference root); the Python mirror of that interface
+ * lives in physics-based-ray-tracing_amd/ and reaches this library through ctypes only.
+ *
+ * Conventions
+ *  - extern "C", plain pointers + sizes, no C++/torch types.
+ *  - every function returns int: 0 = OK, <0 = error class (PBRT_E_*); the message is available
+ *    from pbrt_last_error().  Nothing throws or exits across the ABI.
+ *  - batched leaf ops take HOST pointers to C-contiguous SoA arrays ([component][n], f32/u32);
+ *    the library stages them through its own device buffers.
+ *  - *_dev variants take DEVICE pointers (e.g. torch tensor data_ptr()) and keep data in HBM.
+ *  - one pbrt_ctx per device; calls on a ctx are not re-entrant; all calls are synchronous on
+ *    return (the ctx stream has been synchronised).
+ *  - the caller owns every buffer it passes; the library owns device memory behind the opaque
+ *    handles and retains no caller pointer past a call.
+ */
+#ifndef PBRT_HIP_H
+#define PBRT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBRT_ABI_VERSION 1
+
+/* ---- error classes ------------------------------------------------------------------------ */
+#define PBRT_OK 0
+#define PBRT_E_INVALID (-1) /* bad argument / inconsistent descriptor            */
+#define PBRT_E_DEVICE (-2)  /* HIP runtime error (no device, launch failure ...) */
+#define PBRT_E_NOMEM (-3)   /* host or device allocation failed                  */
+#define PBRT_E_UNSUPPORTED (-4)
+
+/* ---- primitives --------------------------------------------------------------------------- */
+/* One 64-byte record per primitive.  World space, f32.
+ *   TRIANGLE       g = v0[3], e1 = v1-v0 [3], e2 = v2-v0 [3], n = normalize(e1 x e2) [3]
+ *   SPHERE         g = centre[3], radius, 8 x 0
+ *   PARALLELOGRAM  g = corner[3], e1[3], e2[3], n[3]   (Mitsuba 'rectangle' under to_world:
+ *                  corner = T(-1,-1,0), e1 = T(1,-1,0)-corner, e2 = T(-1,1,0)-corner)
+ *   CONE           g = base centre[3], axis (base->apex, length = height)[3], base radius, 5 x 0
+ * The scenes that feed these: scenes/cbox.xml (12 triangles + 2 spheres), scenes/simple.xml
+ * (teapot.ply, 2256 triangles), MitsubaScenes/ *.xml (sphere / rectangle / cone),
+ * TestRing/TestRing.obj (1152 triangles).
+ */
+#define PBRT_PRIM_TRIANGLE 0u
+#define PBRT_PRIM_SPHERE 1u
+#define PBRT_PRIM_PARALLELOGRAM 2u
+#define PBRT_PRIM_CONE 3u
+
+typedef struct pbrt_prim {
+    float g[12];
+    uint32_t type;     /* PBRT_PRIM_*                                   */
+    uint32_t material; /* index into pbrt_scene_desc.materials          */
+    int32_t emitter;   /* index into pbrt_scene_desc.emitters, -1: none */
+    uint32_t shape;    /* caller's shape id (returned untouched)        */
+} pbrt_prim;
+
+/* ---- materials (BSDFs) -------------------------------------------------------------------- */
+/* DIFFUSE     p[0..2] = reflectance                      (Mitsuba 'diffuse', scenes/cbox.xml:36-50)
+ * CONDUCTOR   p[0..2] = specular_reflectance, perfect mirror (Mitsuba 'conductor' default,
+ *                                                          scenes/cbox.xml:54)
+ * DIELECTRIC  p[0] = eta = int_ior / ext_ior             (Mitsuba 'dielectric', scenes/cbox.xml:52)
+ * ULTRA       p[0] = impedance, p[1] = roughness, p[2] = medium_z (1.2)
+ *                                                        (UltraBSDF, CustomBSDF.py:7-26,105)
+ * NONE        absorbs everything
+ */
+#define PBRT_MAT_DIFFUSE 0u
+#define PBRT_MAT_CONDUCTOR 1u
+#define PBRT_MAT_DIELECTRIC 2u
+#define PBRT_MAT_ULTRA 3u
+#define PBRT_MAT_NONE 4u
+
+typedef struct pbrt_material {
+    uint32_t type;
+    float p[7];
+} pbrt_material;
+
+/* ---- emitters ----------------------------------------------------------------------------- */
+/* AREA   radiance; its primitives are light_prims[first .. first+count) with the inclusive,
+ *        normalised area CDF light_cdf[first .. first+count); area = summed surface area.
+ * POINT  radiance = intensity, pos = position.
+ */
+#define PBRT_EMIT_AREA 0u
+#define PBRT_EMIT_POINT 1u
+
+typedef struct pbrt_emitter {
+    uint32_t type;
+    float radiance[3];
+    float pos[3];
+    uint32_t first;
+    uint32_t count;
+    float area;
+    float pad[2];
+} pbrt_emitter;
+
+#define PBRT_ACCEL_AUTO 0u  /* brute force when n_prims <= 32, LDS-resident BVH otherwise */
+#define PBRT_ACCEL_BRUTE 1u /* uniform loop over all primitives (scalar loads)            */
+#define PBRT_ACCEL_BVH 2u   /* BVH2, nodes + primitives staged into LDS per workgroup     */
+
+typedef struct pbrt_scene_desc {
+    uint32_t n_prims;
+    const pbrt_prim *prims;
+    uint32_t n_materials;
+    const pbrt_material *materials;
+    uint32_t n_emitters;
+    const pbrt_emitter *emitters;
+    uint32_t n_light_prims;
+    const uint32_t *light_prims;
+    const float *light_cdf;
+    uint32_t accel; /* PBRT_ACCEL_* */
+} pbrt_scene_desc;
+
+/* ---- camera / film (radiance mode) -------------------------------------------------------- */
+/* Mitsuba 'perspective' sensor (scenes/cbox.xml:11-21, scenes/simple.xml:7-12).
+ * to_world: row-major 3x4 camera-to-world matrix; columns are (left, up, dir, origin).  */
+typedef struct pbrt_camera {
+    float to_world[12];
+    float tan_half_fov_x;
+    float near_clip;
+    float far_clip;
+    uint32_t film_w; /* full film size; crops are given per render call */
+    uint32_t film_h;
+} pbrt_camera;
+
+#define PBRT_FILTER_BOX 0u      /* radius 0.5 (scenes/simple.xml:17) */
+#define PBRT_FILTER_TENT 1u     /* radius 1.0 (scenes/cbox.xml:28)   */
+#define PBRT_FILTER_GAUSSIAN 2u /* stddev 0.5, radius 2.0            */
+
+typedef struct pbrt_film_desc {
+    uint32_t crop_x, crop_y, crop_w, crop_h; /* output window inside the full film      */
+    uint32_t spp;                            /* samples per pixel rendered by this call  */
+    uint32_t sample_offset;                  /* index of the first sample (RNG key)      */
+    uint32_t max_depth;                      /* Mitsuba path 'max_depth' (cbox.xml:4,8)  */
+    uint32_t rr_depth;                       /* Mitsuba path 'rr_depth' (default 5)      */
+    uint32_t filter;                         /* PBRT_FILTER_*                            */
+    uint32_t seed;
+    uint32_t flags;      /* PBRT_FILM_*                                                  */
+    uint32_t pass_paths; /* 0 = library default; paths kept in flight per pass           */
+} pbrt_film_desc;
+
+#define PBRT_FILM_RAW_ACCUM 1u /* output 4 floats/pixel (sum w*rgb, sum w) un-normalised: \
+                                  for sample-sharded multi-GPU reduction */
+
+/* ---- ultrasound (acoustic) mode ----------------------------------------------------------- */
+/* Parameter block of UltraIntegrator (CustomIntegrator.py:13-48) plus the sensor transform
+ * the integrator reads from scene.sensors()[0].transform (CustomIntegrator.py:272). */
+#define PBRT_US_MAX_ANGLES 64
+
+typedef struct pbrt_us_params {
+    uint32_t max_depth;    /* CustomIntegrator.py:16 */
+    float frequency;       /* :17 */
+    float sound_speed;     /* :18 */
+    float attenuation;     /* :19 */
+    float main_beam_angle; /* degrees, :21 */
+    float cutoff_angle;    /* degrees, :22 */
+    float fs;              /* 'sampling_rate', :23 */
+    uint32_t n_elements;   /* :26 */
+    float pitch;           /* :27 */
+    uint32_t n_angles;     /* :33-34 */
+    float angles_deg[PBRT_US_MAX_ANGLES];
+    uint32_t time_samples; /* :42 */
+    float sensor_to_world[12]; /* row-major 3x4 */
+    float max_path_len;        /* hard-coded 0.2 in the reference (:307,372) */
+    uint32_t quirks;           /* PBRT_USQ_* */
+} pbrt_us_params;
+
+/* Behaviour switches; each bit reproduces one reference quirk.
+ * The library default (quirks = PBRT_USQ_REFERENCE) is the literal arithmetic of the scalar
+ * variant simulate_acquisition_parallel (CustomIntegrator.py:235-376) and UltraBSDF.sample
+ * (CustomBSDF.py:87-175) with ONE repair: 'survive' is initialised to True (quirk B5), because
+ * as checked in the loop raises UnboundLocalError on the first surviving bounce. */
+#define PBRT_USQ_DIAG_SAMPLE 0x1u   /* A2: scalar sample broadcast to Point2f(s,s)             */
+#define PBRT_USQ_REF_REFLECT 0x2u   /* A5: reflected = wi + 2 cos m (not the mirror direction) */
+#define PBRT_USQ_UNIT_GGX_PDF 0x4u  /* A7: ggx_pdf == 1.0                                       */
+#define PBRT_USQ_DOUBLE_LOCAL 0x8u  /* A1: Frame(n).to_local applied to the already-local wi   */
+#define PBRT_USQ_MIXED_FRAMES 0x10u /* A8: world shading normal dotted with local wi           */
+#define PBRT_USQ_NEVER_ENTER 0x20u  /* A4: 'entering' is always false                          */
+#define PBRT_USQ_CLAMP_TIME 0x40u   /* B3 (Dr.Jit variant): clamp t_idx instead of dropping    */
+#define PBRT_USQ_NO_TOF_ACCUM 0x80u /* B2 (Dr.Jit variant): tof never accumulates              */
+#define PBRT_USQ_REFERENCE                                                                  \
+    (PBRT_USQ_DIAG_SAMPLE | PBRT_USQ_REF_REFLECT | PBRT_USQ_UNIT_GGX_PDF | PBRT_USQ_DOUBLE_LOCAL | \
+     PBRT_USQ_MIXED_FRAMES | PBRT_USQ_NEVER_ENTER)
+
+/* UltraSensor (bytecode-only class; props used at USMain.py:43-65 and
+ * MitsubaScenes/Sphere_Box.xml:16-34). */
+typedef struct pbrt_us_sensor {
+    uint32_t num_elements;
+    float element_width, element_height, pitch;
+    float radius; /* +inf: linear array */
+    float center_frequency, sound_speed, directivity;
+    float to_world[12];
+} pbrt_us_sensor;
+
+/* CustomEmitter (CustomEmmitter.py:5-49), linear or convex array. */
+typedef struct pbrt_us_emitter {
+    uint32_t number_of_elements;
+    float pitch, element_width, element_height;
+    float radius;        /* 0: linear */
+    float opening_angle; /* degrees   */
+    uint32_t number_of_rays_per_element;
+    float speed_of_sound;
+    float steering_angle_min, steering_angle_max; /* degrees */
+} pbrt_us_emitter;
+
+/* CustomSensor.put_data accumulator (CustomSensor.py:7-59). */
+typedef struct pbrt_us_receiver {
+    uint32_t number_of_elements;
+    float pitch;
+    float sample_rate;
+    uint32_t time_samples;
+} pbrt_us_receiver;
+
+typedef struct pbrt_stats {
+    uint64_t samples;      /* camera / transducer paths started by the last call           */
+    uint64_t segments;     /* path segments shaded (sum over bounces of live paths)         */
+    uint64_t shadow_rays;  /* occlusion rays                                               */
+    double kernel_ms;      /* device time of the last call, HIP events on the ctx stream    */
+    double bounce_ms;      /* of which: the dominant (bounce) kernels                       */
+    uint32_t bounce_launches;
+    uint32_t passes;
+    uint64_t model_bytes;  /* algorithmic HBM bytes of the last call (DESIGN.md byte model) */
+    uint64_t bounce_model_bytes;
+} pbrt_stats;
+
+typedef struct pbrt_ctx pbrt_ctx;
+typedef struct pbrt_scene pbrt_scene;
+
+/* ---- context / scene ---------------------------------------------------------------------- */
+int pbrt_abi_version(void);
+/* replaces: mi.set_variant(...) (USMain.py:12) -- selects the device instead of a JIT backend */
+int pbrt_ctx_create(int device, pbrt_ctx **out);
+int pbrt_ctx_destroy(pbrt_ctx *ctx);
+const char *pbrt_last_error(pbrt_ctx *ctx); /* ctx may be NULL: last ctx-less error */
+int pbrt_get_stats(pbrt_ctx *ctx, pbrt_stats *out);
+
+/* replaces: mi.load_dict / mi.load_file scene instantiation + accel build (USMain.py:257) */
+int pbrt_scene_create(pbrt_ctx *ctx, const pbrt_scene_desc *desc, pbrt_scene **out);
+/* replaces: params[key] = v; params.update() (USMain.py:264-265) -> BSDF.parameters_changed
+ * (CustomBSDF.py:186-191).  Overwrites material `index` in place, no accel rebuild. */
+int pbrt_scene_update_material(pbrt_scene *scene, uint32_t index, const pbrt_material *m);
+int pbrt_scene_destroy(pbrt_scene *scene);
+
+/* ---- the hot path: radiance mode ----------------------------------------------------------- */
+/* replaces: mi.render(scene) == SamplingIntegrator::render -> Sensor.sample_ray ->
+ * Integrator.sample (CustomIntegrator.py:52-53 is the stub; semantics SURVEY.md App. D) ->
+ * film.  out_rgb: host float[crop_h*crop_w*3] (or *4 with PBRT_FILM_RAW_ACCUM). */
+int pbrt_render_radiance(pbrt_scene *scene, const pbrt_camera *cam, const pbrt_film_desc *film, float *out_rgb);
+/* same, output left in HBM at device pointer d_out (no PCIe copy) */
+int pbrt_render_radiance_dev(pbrt_scene *scene, const pbrt_camera *cam, const pbrt_film_desc *film, void *d_out);
+
+/* replaces: Integrator.sample(scene, sampler, ray, medium, active) -> (spec, mask, aovs)
+ * (CustomIntegrator.py:52-53 is a stub returning 0; radiance semantics SURVEY.md App. D).
+ * Radiance arriving along n caller-supplied rays: o,d [3][n] (unit d), tmax [n]; the RNG key of ray i
+ * is (index_offset + i, sample_index).  out rgb [3][n]. */
+int pbrt_integrator_sample(pbrt_scene *scene, uint32_t n, const float *o, const float *d, const float *tmax,
+                           uint32_t index_offset, uint32_t sample_index, uint32_t seed, uint32_t max_depth,
+                           uint32_t rr_depth, float *rgb);
+
+/* ---- the hot path: ultrasound mode ---------------------------------------------------------- */
+/* replaces: UltraIntegrator.simulate_acquisition_parallel(scene) (CustomIntegrator.py:235-405),
+ * called from USMain.py:99.  Traces paths k in [path_offset, path_offset+paths_per_ray) for
+ * every (angle, element) pair; channel_buf[(a*n_elements+recv)*time_samples + t] accumulates the
+ * echoes divided by norm_paths (pass the TOTAL paths per ray of the job so that shards sum to
+ * the single-device result); tx_delays[a*n_elements+e] as CustomIntegrator.py:254-257. */
+int pbrt_us_acquire(pbrt_scene *scene, const pbrt_us_params *p, uint32_t seed, uint32_t paths_per_ray,
+                    uint32_t path_offset, uint32_t norm_paths, float *channel_buf, float *tx_delays);
+int pbrt_us_acquire_dev(pbrt_scene *scene, const pbrt_us_params *p, uint32_t seed, uint32_t paths_per_ray,
+                        uint32_t path_offset, uint32_t norm_paths, void *d_channel_buf, float *tx_delays);
+
+/* ---- batched leaf operators (host SoA in/out) ---------------------------------------------- */
+/* replaces: scene.ray_intersect(ray) (CustomIntegrator.py:146,309).  o,d: [3][n]; tmax: [n];
+ * out t [n] (+inf: miss), prim [n] (0xffffffff: miss), u,v [n]. */
+int pbrt_ray_intersect(pbrt_scene *scene, uint32_t n, const float *o, const float *d, const float *tmax, float *t,
+                       uint32_t *prim, float *u, float *v);
+/* replaces: scene.ray_intersect(si.spawn_ray(sec_dir)).is_valid() used as an occlusion test
+ * (CustomIntegrator.py:159-160,324-325).  hit [n] is 0/1. */
+int pbrt_ray_test(pbrt_scene *scene, uint32_t n, const float *o, const float *d, const float *tmax, uint8_t *hit);
+
+/* replaces: BSDF.sample(ctx, si, sample1, sample2) (CustomBSDF.py:87-175 for ULTRA; Mitsuba
+ * diffuse / conductor / dielectric per SURVEY.md App. D).
+ *  wi      [3][n] incident direction in the local shading frame (si.wi)
+ *  n_geo   [3][n] world geometric normal (si.n)        -- read by ULTRA only
+ *  n_sh    [3][n] world shading normal (si.sh_frame.n) -- read by ULTRA only
+ *  s1 [n], s2 [2][n] the uniform variates
+ *  out: wo [3][n] local, pdf [n], weight [3][n] (ULTRA: amplitude in weight[0], rest equal),
+ *       sampled [n]: 0 = reflection lobe, 1 = transmission lobe, 0xffffffff = invalid sample */
+int pbrt_bsdf_sample(pbrt_ctx *ctx, const pbrt_material *m, uint32_t quirks, uint32_t n, const float *wi,
+                     const float *n_geo, const float *n_sh, const float *s1, const float *s2, float *wo, float *pdf,
+                     float *weight, uint32_t *sampled);
+/* replaces: BSDF.eval / BSDF.pdf / BSDF.eval_pdf (CustomBSDF.py:177-184: constant 0 for ULTRA).
+ * f [3][n] = bsdf value * cos(theta_o). */
+int pbrt_bsdf_eval_pdf(pbrt_ctx *ctx, const pbrt_material *m, uint32_t n, const float *wi, const float *wo, float *f,
+                       float *pdf);
+
+/* Emitter.sample_direction(it, sample) -- required by the north star, absent from the
+ * reference; semantics of Mitsuba area / point emitters.  No visibility test.
+ *  p [3][n] reference points; u [4][n] variates (emitter pick, primitive pick, 2-D position)
+ *  out: d [3][n], dist [n], pdf [n] (solid angle; 1 for delta), weight [3][n] = radiance/pdf,
+ *       q [3][n] sampled point, emitter [n] */
+int pbrt_emitter_sample_direction(pbrt_scene *scene, uint32_t n, const float *p, const float *u, float *d, float *dist,
+                                  float *pdf, float *weight, float *q, uint32_t *emitter);
+
+/* replaces: Sensor.sample_ray of the Mitsuba 'perspective' sensor. pos [2][n] in [0,1)^2 over
+ * the full film.  out: o,d [3][n], tmax [n]. */
+int pbrt_sensor_sample_ray(pbrt_ctx *ctx, const pbrt_camera *cam, uint32_t n, const float *pos, float *o, float *d,
+                           float *tmax);
+
+/* replaces: UltraSensor.sample_ray(time, wavelength_sample, position_sample, aperture_sample)
+ * (SURVEY.md App. C).  time, wavelength_sample [n]; position_sample, aperture_sample [2][n].
+ * use_hemisphere_warp != 0 selects the warp.square_to_uniform_hemisphere branch. */
+int pbrt_us_sensor_sample_ray(pbrt_ctx *ctx, const pbrt_us_sensor *s, int use_hemisphere_warp, uint32_t n,
+                              const float *time, const float *wavelength_sample, const float *position_sample,
+                              const float *aperture_sample, float *o, float *d, float *weight);
+
+/* replaces: CustomEmitter.sample_ray(time, sample1, sample2, sample3) (CustomEmmitter.py:81-107)
+ * incl. sample_position (:51-79).  time, s1, s3 [n]; s2 [2][n].
+ * out: o,d [3][n], ray_time [n], weight [n], pdf_pos [n]. */
+int pbrt_us_emitter_sample_ray(pbrt_ctx *ctx, const pbrt_us_emitter *e, uint32_t n, const float *time,
+                               const float *s1, const float *s2, const float *s3, float *o, float *d, float *ray_time,
+                               float *weight, float *pdf_pos);
+
+/* replaces: CustomSensor.put_data(ray, amplitude) (CustomSensor.py:29-59), batched: ray origin
+ * x [n], ray time [n], ray direction [3][n], amplitude [n] accumulated into
+ * channel_buffer[number_of_elements*time_samples] (host, read-modify-write). */
+int pbrt_us_put_data(pbrt_ctx *ctx, const pbrt_us_receiver *r, uint32_t n, const float *ox, const float *time,
+                     const float *d, const float *amplitude, float *channel_buffer);
+
+/* tx_delay[a,e] = elem_x[e] * sin(theta_a) / c  (CustomIntegrator.py:246-257); host-only helper
+ * shared by pbrt_us_acquire. */
+int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx_delays);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBRT_HIP_H */

@@ -1,0 +1,284 @@
+"""ctypes binding of libpbrt_hip.so (include/pbrt_hip.h).
+
+This is the ONLY way the Python host reaches the HIP path.  There is no CPU fallback: if the
+shared library is missing, or no MI355X is visible, every compute entry point raises.
+The structures below mirror include/pbrt_hip.h field for field.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpbrt_hip.so")
+
+PBRT_ABI_VERSION = 1
+
+# primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
+PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
+MAT_DIFFUSE, MAT_CONDUCTOR, MAT_DIELECTRIC, MAT_ULTRA, MAT_NONE = 0, 1, 2, 3, 4
+EMIT_AREA, EMIT_POINT = 0, 1
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
+FILM_RAW_ACCUM = 1
+US_MAX_ANGLES = 64
+
+USQ_DIAG_SAMPLE = 0x1
+USQ_REF_REFLECT = 0x2
+USQ_UNIT_GGX_PDF = 0x4
+USQ_DOUBLE_LOCAL = 0x8
+USQ_MIXED_FRAMES = 0x10
+USQ_NEVER_ENTER = 0x20
+USQ_CLAMP_TIME = 0x40
+USQ_NO_TOF_ACCUM = 0x80
+USQ_REFERENCE = (USQ_DIAG_SAMPLE | USQ_REF_REFLECT | USQ_UNIT_GGX_PDF | USQ_DOUBLE_LOCAL
+                 | USQ_MIXED_FRAMES | USQ_NEVER_ENTER)
+
+PRIM_DTYPE = np.dtype([("g", np.float32, 12), ("type", np.uint32), ("material", np.uint32),
+                       ("emitter", np.int32), ("shape", np.uint32)])
+MATERIAL_DTYPE = np.dtype([("type", np.uint32), ("p", np.float32, 7)])
+EMITTER_DTYPE = np.dtype([("type", np.uint32), ("radiance", np.float32, 3), ("pos", np.float32, 3),
+                          ("first", np.uint32), ("count", np.uint32), ("area", np.float32),
+                          ("pad", np.float32, 2)])
+assert PRIM_DTYPE.itemsize == 64 and MATERIAL_DTYPE.itemsize == 32 and EMITTER_DTYPE.itemsize == 48
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("p", C.c_float * 7)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_prims", C.c_uint32), ("prims", C.c_void_p),
+                ("n_materials", C.c_uint32), ("materials", C.c_void_p),
+                ("n_emitters", C.c_uint32), ("emitters", C.c_void_p),
+                ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("light_cdf", C.c_void_p),
+                ("accel", C.c_uint32)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("to_world", C.c_float * 12), ("tan_half_fov_x", C.c_float), ("near_clip", C.c_float),
+                ("far_clip", C.c_float), ("film_w", C.c_uint32), ("film_h", C.c_uint32)]
+
+
+class FilmDesc(C.Structure):
+    _fields_ = [("crop_x", C.c_uint32), ("crop_y", C.c_uint32), ("crop_w", C.c_uint32), ("crop_h", C.c_uint32),
+                ("spp", C.c_uint32), ("sample_offset", C.c_uint32), ("max_depth", C.c_uint32),
+                ("rr_depth", C.c_uint32), ("filter", C.c_uint32), ("seed", C.c_uint32), ("flags", C.c_uint32),
+                ("pass_paths", C.c_uint32)]
+
+
+class UsParams(C.Structure):
+    _fields_ = [("max_depth", C.c_uint32), ("frequency", C.c_float), ("sound_speed", C.c_float),
+                ("attenuation", C.c_float), ("main_beam_angle", C.c_float), ("cutoff_angle", C.c_float),
+                ("fs", C.c_float), ("n_elements", C.c_uint32), ("pitch", C.c_float), ("n_angles", C.c_uint32),
+                ("angles_deg", C.c_float * US_MAX_ANGLES), ("time_samples", C.c_uint32),
+                ("sensor_to_world", C.c_float * 12), ("max_path_len", C.c_float), ("quirks", C.c_uint32)]
+
+
+class UsSensor(C.Structure):
+    _fields_ = [("num_elements", C.c_uint32), ("element_width", C.c_float), ("element_height", C.c_float),
+                ("pitch", C.c_float), ("radius", C.c_float), ("center_frequency", C.c_float),
+                ("sound_speed", C.c_float), ("directivity", C.c_float), ("to_world", C.c_float * 12)]
+
+
+class UsEmitter(C.Structure):
+    _fields_ = [("number_of_elements", C.c_uint32), ("pitch", C.c_float), ("element_width", C.c_float),
+                ("element_height", C.c_float), ("radius", C.c_float), ("opening_angle", C.c_float),
+                ("number_of_rays_per_element", C.c_uint32), ("speed_of_sound", C.c_float),
+                ("steering_angle_min", C.c_float), ("steering_angle_max", C.c_float)]
+
+
+class UsReceiver(C.Structure):
+    _fields_ = [("number_of_elements", C.c_uint32), ("pitch", C.c_float), ("sample_rate", C.c_float),
+                ("time_samples", C.c_uint32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("kernel_ms", C.c_double), ("bounce_ms", C.c_double), ("bounce_launches", C.c_uint32),
+                ("passes", C.c_uint32), ("model_bytes", C.c_uint64), ("bounce_model_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_P = C.c_void_p
+_F = C.c_void_p  # float* passed as raw address of a numpy buffer
+
+# name -> (restype, argtypes); every symbol include/pbrt_hip.h declares
+SIGNATURES = {
+    "pbrt_abi_version": (C.c_int, []),
+    "pbrt_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "pbrt_ctx_destroy": (C.c_int, [_P]),
+    "pbrt_last_error": (C.c_char_p, [_P]),
+    "pbrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "pbrt_scene_create": (C.c_int, [_P, C.POINTER(SceneDesc), C.POINTER(_P)]),
+    "pbrt_scene_update_material": (C.c_int, [_P, C.c_uint32, C.POINTER(Material)]),
+    "pbrt_scene_destroy": (C.c_int, [_P]),
+    "pbrt_render_radiance": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(FilmDesc), _F]),
+    "pbrt_render_radiance_dev": (C.c_int, [_P, C.POINTER(Camera), C.POINTER(FilmDesc), _P]),
+    "pbrt_integrator_sample": (C.c_int, [_P, C.c_uint32, _F, _F, _F, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_uint32, _F]),
+    "pbrt_us_acquire": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _F, _F]),
+    "pbrt_us_acquire_dev": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _F]),
+    "pbrt_ray_intersect": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_ray_test": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F]),
+    "pbrt_bsdf_sample": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_bsdf_eval_pdf": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, _F, _F, _F, _F]),
+    "pbrt_emitter_sample_direction": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_sensor_sample_ray": (C.c_int, [_P, C.POINTER(Camera), C.c_uint32, _F, _F, _F, _F]),
+    "pbrt_us_sensor_sample_ray": (C.c_int, [_P, C.POINTER(UsSensor), C.c_int, C.c_uint32, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_us_emitter_sample_ray": (C.c_int, [_P, C.POINTER(UsEmitter), C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_us_put_data": (C.c_int, [_P, C.POINTER(UsReceiver), C.c_uint32, _F, _F, _F, _F, _F]),
+    "pbrt_us_tx_delays": (C.c_int, [C.POINTER(UsParams), _F]),
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None):
+    """dlopen libpbrt_hip.so and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryMissing(
+            f"{p} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the ray-transport hot path.")
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.pbrt_abi_version()
+    if ver != PBRT_ABI_VERSION:
+        raise RuntimeError(f"libpbrt_hip.so ABI {ver} != binding {PBRT_ABI_VERSION}")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def addr(a: np.ndarray | None):
+    """Raw address of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def mat12(m) -> "C.Array":
+    """3x4 row-major float[12] from a 4x4 (or 3x4) matrix."""
+    a = np.asarray(m, dtype=np.float64)[:3, :4].astype(np.float32).ravel()
+    return (C.c_float * 12)(*a.tolist())
+
+
+def make_material(mtype: int, params) -> Material:
+    m = Material()
+    m.type = mtype
+    p = list(params) + [0.0] * (7 - len(params))
+    for i in range(7):
+        m.p[i] = float(p[i])
+    return m
+
+
+class Context:
+    """One pbrt_ctx per device (include/pbrt_hip.h).  Raises RuntimeError on any non-zero rc."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = _P()
+        rc = self.lib.pbrt_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self.lib.pbrt_last_error(None)
+            raise RuntimeError(f"pbrt_ctx_create(device={device}) failed rc={rc}: {msg.decode() if msg else ''}")
+        self.handle = h
+        self.device = device
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            msg = self.lib.pbrt_last_error(self.handle)
+            raise RuntimeError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+
+    def stats(self) -> dict:
+        st = Stats()
+        self.check(self.lib.pbrt_get_stats(self.handle, C.byref(st)), "pbrt_get_stats")
+        return st.as_dict()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.pbrt_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if "PBRT_DEVICE" not in os.environ else int(os.environ["PBRT_DEVICE"])
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+def fill_scene_desc(prims: np.ndarray, materials: np.ndarray, emitters: np.ndarray, light_prims: np.ndarray,
+                    light_cdf: np.ndarray, accel: int = ACCEL_AUTO) -> SceneDesc:
+    """The arrays must stay alive while the returned descriptor is in use."""
+    assert prims.dtype == PRIM_DTYPE and materials.dtype == MATERIAL_DTYPE and emitters.dtype == EMITTER_DTYPE
+    d = SceneDesc()
+    d.n_prims = len(prims)
+    d.prims = addr(prims)
+    d.n_materials = len(materials)
+    d.materials = addr(materials)
+    d.n_emitters = len(emitters)
+    d.emitters = addr(emitters) if len(emitters) else None
+    d.n_light_prims = len(light_prims)
+    d.light_prims = addr(light_prims) if len(light_prims) else None
+    d.light_cdf = addr(light_cdf) if len(light_cdf) else None
+    d.accel = accel
+    return d
+
+
+class DeviceScene:
+    """pbrt_scene handle: device-resident primitives / materials / emitters (+ BVH)."""
+
+    def __init__(self, ctx: Context, prims, materials, emitters, light_prims, light_cdf, accel=ACCEL_AUTO):
+        self.ctx = ctx
+        self._keep = (prims, materials, emitters, light_prims, light_cdf)
+        desc = fill_scene_desc(prims, materials, emitters, light_prims, light_cdf, accel)
+        h = _P()
+        ctx.check(ctx.lib.pbrt_scene_create(ctx.handle, C.byref(desc), C.byref(h)), "pbrt_scene_create")
+        self.handle = h
+        self.n_prims = len(prims)
+
+    def update_material(self, index: int, m: Material):
+        self.ctx.check(self.ctx.lib.pbrt_scene_update_material(self.handle, int(index), C.byref(m)),
+                       "pbrt_scene_update_material")
+
+    def close(self):
+        if getattr(self, "handle", None) and self.ctx.handle:
+            self.ctx.lib.pbrt_scene_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,182 @@
+// bvh_build.h -- host-side BVH2 builder (binned SAH, <= 4 primitives per leaf) for scenes that do
+// not fit the brute-force loop (scenes/meshes/teapot.ply: 2256 triangles, TestRing/TestRing.obj:
+// 1152 triangles).  Output is the flat DevNode array the kernels stage into LDS, the primitives in
+// leaf order, and the map from leaf-order slot to the caller's primitive index.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/pbrt_hip.h"
+
+struct HostNode {
+    float lo[3];
+    uint32_t a;
+    float hi[3];
+    uint32_t b;
+};
+
+struct HostBvh {
+    std::vector<HostNode> nodes;
+    std::vector<uint32_t> order;  // leaf-order slot -> caller index
+    uint32_t max_depth = 0;
+};
+
+namespace bvh_detail {
+
+struct Box {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    void grow(const Box &o) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], o.lo[k]);
+            hi[k] = std::max(hi[k], o.hi[k]);
+        }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return (dx < 0) ? 0.0f : 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+inline Box prim_box(const pbrt_prim &P) {
+    Box b;
+    if (P.type == PBRT_PRIM_SPHERE) {
+        for (int k = 0; k < 3; ++k) {
+            b.lo[k] = P.g[k] - P.g[3];
+            b.hi[k] = P.g[k] + P.g[3];
+        }
+        return b;
+    }
+    for (int k = 0; k < 3; ++k) {
+        float c0 = P.g[k], c1 = P.g[k] + P.g[3 + k], c2 = P.g[k] + P.g[6 + k];
+        float c3 = P.type == PBRT_PRIM_PARALLELOGRAM ? P.g[k] + P.g[3 + k] + P.g[6 + k] : c0;
+        b.lo[k] = std::min(std::min(c0, c1), std::min(c2, c3));
+        b.hi[k] = std::max(std::max(c0, c1), std::max(c2, c3));
+    }
+    return b;
+}
+
+struct Builder {
+    const pbrt_prim *prims;
+    std::vector<Box> boxes;
+    std::vector<float> cent;
+    HostBvh *out;
+    float pad;
+
+    // nodes[idx] must already exist
+    void build(uint32_t idx, uint32_t first, uint32_t count, uint32_t depth) {
+        out->max_depth = std::max(out->max_depth, depth);
+        Box bb, cb;
+        for (uint32_t k = 0; k < count; ++k) {
+            uint32_t i = out->order[first + k];
+            bb.grow(boxes[i]);
+            for (int c = 0; c < 3; ++c) {
+                cb.lo[c] = std::min(cb.lo[c], cent[3 * i + c]);
+                cb.hi[c] = std::max(cb.hi[c], cent[3 * i + c]);
+            }
+        }
+        HostNode n;
+        for (int c = 0; c < 3; ++c) {
+            n.lo[c] = bb.lo[c] - pad;
+            n.hi[c] = bb.hi[c] + pad;
+        }
+        const int NB = 16;
+        int best_axis = -1, best_split = -1;
+        float best_cost = (float)count * bb.area();  // leaf cost
+        if (count > 4) best_cost = INFINITY;         // force a split above the leaf limit
+        for (int axis = 0; axis < 3 && count > 1; ++axis) {
+            float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
+            if (!(ext > 0)) continue;
+            Box bins[NB];
+            uint32_t cnt[NB] = {0};
+            for (uint32_t k = 0; k < count; ++k) {
+                uint32_t i = out->order[first + k];
+                int b = std::min(NB - 1, (int)((cent[3 * i + axis] - lo) / ext * NB));
+                bins[b].grow(boxes[i]);
+                cnt[b]++;
+            }
+            float la[NB], ra[NB];
+            uint32_t lc[NB], rc[NB];
+            Box acc;
+            uint32_t c = 0;
+            for (int b = 0; b < NB; ++b) {
+                acc.grow(bins[b]);
+                c += cnt[b];
+                la[b] = acc.area();
+                lc[b] = c;
+            }
+            acc = Box();
+            c = 0;
+            for (int b = NB - 1; b >= 0; --b) {
+                acc.grow(bins[b]);
+                c += cnt[b];
+                ra[b] = acc.area();
+                rc[b] = c;
+            }
+            for (int b = 0; b + 1 < NB; ++b) {
+                if (lc[b] == 0 || rc[b + 1] == 0) continue;
+                float cost = 0.5f * bb.area() + la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    best_axis = axis;
+                    best_split = b;
+                }
+            }
+        }
+        uint32_t mid = 0;
+        if (best_axis >= 0) {
+            float lo = cb.lo[best_axis], ext = cb.hi[best_axis] - lo;
+            auto it = std::partition(out->order.begin() + first, out->order.begin() + first + count, [&](uint32_t i) {
+                int b = std::min(NB - 1, (int)((cent[3 * i + best_axis] - lo) / ext * NB));
+                return b <= best_split;
+            });
+            mid = (uint32_t)(it - (out->order.begin() + first));
+        } else if (count > 8) {  // degenerate centroids: split in the middle
+            best_axis = 0;
+            mid = count / 2;
+        }
+        if (best_axis < 0 || mid == 0 || mid == count) {
+            n.a = first;
+            n.b = count;  // leaf (count <= 8 guaranteed by the branch above)
+            out->nodes[idx] = n;
+            return;
+        }
+        uint32_t left = (uint32_t)out->nodes.size();
+        out->nodes.push_back(HostNode{});
+        out->nodes.push_back(HostNode{});
+        n.a = left;
+        n.b = 0x80000000u | (uint32_t)best_axis;
+        out->nodes[idx] = n;
+        build(left, first, mid, depth + 1);
+        build(left + 1, first + mid, count - mid, depth + 1);
+    }
+};
+
+}  // namespace bvh_detail
+
+inline void build_bvh(const pbrt_prim *prims, uint32_t n, HostBvh *out) {
+    bvh_detail::Builder b;
+    b.prims = prims;
+    b.out = out;
+    b.boxes.resize(n);
+    b.cent.resize(3 * (size_t)n);
+    out->order.resize(n);
+    bvh_detail::Box all;
+    for (uint32_t i = 0; i < n; ++i) {
+        b.boxes[i] = bvh_detail::prim_box(prims[i]);
+        all.grow(b.boxes[i]);
+        for (int c = 0; c < 3; ++c) b.cent[3 * i + c] = 0.5f * (b.boxes[i].lo[c] + b.boxes[i].hi[c]);
+        out->order[i] = i;
+    }
+    float dx = all.hi[0] - all.lo[0], dy = all.hi[1] - all.lo[1], dz = all.hi[2] - all.lo[2];
+    float diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+    float mag = 0;
+    for (int c = 0; c < 3; ++c) mag = std::max(mag, std::max(std::fabs(all.lo[c]), std::fabs(all.hi[c])));
+    // conservative padding: the slab test may never cull a primitive the brute-force loop would hit
+    b.pad = 2e-5f * (diag + mag) + 1e-30f;
+    out->nodes.clear();
+    out->nodes.push_back(HostNode{});
+    out->max_depth = 0;
+    b.build(0, 0, n, 0);
+}

@@ -1,0 +1,431 @@
+// device_scene.h -- scene access, intersection, BSDFs, emitter sampling and the perspective
+// sensor on the device.  Semantics: Mitsuba 3 built-ins for radiance mode,
+// the reference's own UltraBSDF arithmetic (CustomBSDF.py:30-175) for ultrasound mode.
+#pragma once
+#include "../../include/pbrt_hip.h"
+#include "device_math.h"
+
+// BVH2 node, 32 bytes.  leaf: a = first primitive (leaf order), b = count (1..8);
+// internal: a = index of the left child (right child = a + 1), b = 0x80000000 | split axis.
+struct DevNode {
+    float lo[3];
+    uint32_t a;
+    float hi[3];
+    uint32_t b;
+};
+
+struct DevScene {
+    const pbrt_prim *prims;  // BRUTE: caller order.  BVH: leaf order
+    const uint32_t *prim_ids;  // BVH: leaf-order slot -> caller's primitive index (nullptr for BRUTE)
+    const DevNode *nodes;
+    const pbrt_material *mats;
+    const pbrt_emitter *emitters;
+    const uint32_t *light_prims;  // caller's primitive indices
+    const float *light_cdf;
+    const pbrt_prim *prims_by_id;  // caller order (== prims for BRUTE); used by emitter sampling
+    uint32_t n_prims, n_nodes, n_emitters, n_mats;
+};
+
+struct Hit {
+    float t, u, v;
+    uint32_t prim;  // caller's primitive index
+    uint32_t slot;  // index into sc.prims
+};
+
+DEV V3 g3(const pbrt_prim &P, int i) { return {P.g[i], P.g[i + 1], P.g[i + 2]}; }
+
+// One primitive against one ray; identical arithmetic to the oracle's prim_hit (Mitsuba
+// Mesh::ray_intersect_triangle / Sphere / Rectangle reached via scene.ray_intersect,
+// CustomIntegrator.py:309).  The barycentric test runs on det-scaled values so that the division
+// is only executed for accepted candidates.
+DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u, float *v) {
+    const uint32_t type = P.type;
+    if (type == PBRT_PRIM_SPHERE) {
+        V3 c = g3(P, 0);
+        float r = P.g[3];
+        V3 f = o - c;
+        float bp = -dot(f, d);
+        V3 perp = madd(d, bp, f);
+        float disc = fma_(r, r, -dot(perp, perp));
+        if (!(disc >= 0.0f)) return false;
+        float sq = sqrtf(disc);
+        float q = bp + copysignf(sq, bp);
+        float cc = fma_(-r, r, dot(f, f));
+        float t0 = cc / q, t1 = q;
+        float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+        if (!(tn <= tmax && tf >= 0.0f)) return false;
+        if (tn < 0.0f && tf > tmax) return false;
+        *t = tn < 0.0f ? tf : tn;
+        *u = 0.0f;
+        *v = 0.0f;
+        return true;
+    }
+    if (type == PBRT_PRIM_TRIANGLE || type == PBRT_PRIM_PARALLELOGRAM) {
+        V3 v0 = g3(P, 0), e1 = g3(P, 3), e2 = g3(P, 6);
+        V3 pvec = cross(d, e2);
+        float det = dot(e1, pvec);
+        V3 tvec = o - v0;
+        V3 qvec = cross(tvec, e1);
+        float us = dot(tvec, pvec), vs = dot(d, qvec), ts = dot(e2, qvec);
+        if (det < 0.0f) {
+            det = -det;
+            us = -us;
+            vs = -vs;
+            ts = -ts;
+        }
+        bool ok = det > 0.0f && us >= 0.0f && vs >= 0.0f && ts >= 0.0f;
+        if (type == PBRT_PRIM_TRIANGLE)
+            ok = ok && (us + vs <= det);
+        else
+            ok = ok && (us <= det) && (vs <= det);
+        if (!ok) return false;
+        float inv = 1.0f / det;
+        float tt = ts * inv;
+        if (!(tt <= tmax)) return false;
+        *t = tt;
+        *u = us * inv;
+        *v = vs * inv;
+        return true;
+    }
+    return false;
+}
+
+// ---- brute force: every lane walks the same primitive sequence, so the records come through the
+// scalar cache (s_load) and cost no vector memory traffic -----------------------------------------
+template <bool ANY>
+DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
+    bool found = false;
+    float best = tmax;
+    for (uint32_t i = 0; i < sc.n_prims; ++i) {
+        float t, u, v;
+        if (prim_hit(sc.prims[i], o, d, best, &t, &u, &v)) {
+            if (ANY) return true;
+            if (!found || t < best) {
+                best = t;
+                h->t = t;
+                h->u = u;
+                h->v = v;
+                h->prim = i;
+                h->slot = i;
+                found = true;
+            }
+        }
+    }
+    return found;
+}
+
+// ---- BVH2 traversal; NodeP / PrimP are global or LDS pointers ----------------------------------
+template <bool ANY, typename NodeP, typename PrimP, typename IdP>
+DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
+    const V3 inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
+    uint32_t stack[32];
+    int sp = 0;
+    uint32_t node = 0;
+    bool found = false;
+    float best = tmax;
+    for (;;) {
+        const float lox = nodes[node].lo[0], loy = nodes[node].lo[1], loz = nodes[node].lo[2];
+        const float hix = nodes[node].hi[0], hiy = nodes[node].hi[1], hiz = nodes[node].hi[2];
+        const uint32_t na = nodes[node].a, nb = nodes[node].b;
+        float tx0 = (lox - o.x) * inv.x, tx1 = (hix - o.x) * inv.x;
+        float ty0 = (loy - o.y) * inv.y, ty1 = (hiy - o.y) * inv.y;
+        float tz0 = (loz - o.z) * inv.z, tz1 = (hiz - o.z) * inv.z;
+        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best));
+        bool descend = false;
+        if (tn <= tf) {
+            if (nb & 0x80000000u) {
+                const uint32_t axis = nb & 3u;
+                const float dax = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
+                const uint32_t near_c = dax < 0.0f ? na + 1 : na, far_c = dax < 0.0f ? na : na + 1;
+                stack[sp++] = far_c;
+                node = near_c;
+                descend = true;
+            } else {
+                for (uint32_t k = 0; k < nb; ++k) {
+                    const uint32_t slot = na + k;
+                    float t, u, v;
+                    if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
+                        if (ANY) return true;
+                        const uint32_t id = prim_ids[slot];
+                        if (!found || t < best || (t == best && id < h->prim)) {
+                            best = t;
+                            h->t = t;
+                            h->u = u;
+                            h->v = v;
+                            h->prim = id;
+                            h->slot = slot;
+                            found = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (!descend) {
+            if (sp == 0) break;
+            node = stack[--sp];
+        }
+    }
+    return found;
+}
+
+// ---- surface interaction ------------------------------------------------------------------------
+struct SI {
+    V3 p, n;
+};
+DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
+    SI si;
+    if (P.type == PBRT_PRIM_SPHERE) {
+        V3 c = g3(P, 0);
+        V3 p = madd(d, t, o);
+        si.n = normalize(p - c);
+        si.p = madd(si.n, P.g[3], c);
+    } else {
+        si.p = madd(g3(P, 6), v, madd(g3(P, 3), u, g3(P, 0)));
+        si.n = g3(P, 9);
+    }
+    return si;
+}
+
+// ---- UltraBSDF.sample: CustomBSDF.py:87-175 (+ _ggx_sample :30-61, ggx_pdf :64-83) --------------
+struct UltraOut {
+    V3 chosen;
+    float pdf, amp;
+    bool reflect;
+};
+DEV UltraOut ultra_core(const pbrt_material &m, uint32_t quirks, V3 wi_in, V3 n_geo, V3 n_sh, float s1, float s2,
+                        float s1b) {
+    const float impedance = m.p[0], alpha = m.p[1], medium_z = m.p[2];
+    V3 wi = wi_in;
+    if (quirks & PBRT_USQ_DOUBLE_LOCAL) wi = to_local(make_frame(n_geo), wi_in);  // :32-33
+    V3 ws = normalize(v3(alpha * wi.x, alpha * wi.y, wi.z));                     // :37-38
+    float inv_len = 1.0f / sqrtf(fmaxf(fma_(-ws.z, ws.z, 1.0f), 1e-7f));          // :41
+    V3 T1 = {ws.y * inv_len, -ws.x * inv_len, 0.0f};                              // :42-44
+    V3 T2 = cross(ws, T1);                                                        // :45
+    float dx, dy;
+    if (quirks & PBRT_USQ_DIAG_SAMPLE)
+        square_to_disk(s1, s1, &dx, &dy);  // :48
+    else
+        square_to_disk(s1, s1b, &dx, &dy);
+    float S = 0.5f * (1.0f + ws.z);                                               // :51
+    dy = fma_(1.0f - S, sqrtf(fmaxf(fma_(-dx, dx, 1.0f), 0.0f)), S * dy);          // :52
+    float mz = sqrtf(fmaxf(1.0f - fma_(dx, dx, dy * dy), 0.0f));                   // :55
+    V3 ms = madd(ws, mz, madd(T2, dy, T1 * dx));                                  // :55
+    V3 mm = normalize(v3(alpha * ms.x, alpha * ms.y, ms.z));                      // :56-59
+    V3 inc = wi_in;                                                               // :90
+    if (!(dot(mm, inc) < 0.0f)) mm = -mm;                                         // :100
+    float cos_wi_m = dot(inc, mm);                                                // :101
+    bool entering;
+    if (quirks & PBRT_USQ_NEVER_ENTER)
+        entering = dot(mm, inc) > 0.0f;  // :104
+    else
+        entering = wi_in.z > 0.0f;
+    float Z1 = entering ? medium_z : impedance;                                   // :106
+    float Z2 = entering ? impedance : medium_z;                                   // :107
+    float ratio = Z1 / Z2;                                                        // :111
+    float cosTr = fabsf(dot(mm, inc));                                            // :119
+    float sqrt_arg = fma_(-(ratio * ratio), fma_(-cosTr, cosTr, 1.0f), 1.0f);      // :120
+    float cosTt = sqrtf(fmaxf(sqrt_arg, 0.0f));                                   // :121
+    float denom = fma_(Z1, cosTr, Z2 * cosTt);                                    // :122
+    float Ar = fma_(Z1, cosTr, -(Z2 * cosTt)) / denom;                            // :123
+    float At = 1.0f - Ar;                                                         // :124
+    V3 refl, trans;
+    if (quirks & PBRT_USQ_REF_REFLECT) {
+        refl = madd(mm, 2.0f * cos_wi_m, inc);                                    // :130
+        trans = madd(mm, fma_(ratio, cosTr, -cosTt), refl * ratio);               // :131
+    } else {
+        refl = madd(mm, 2.0f * cos_wi_m, -inc);
+        trans = madd(mm, -fma_(ratio, cosTr, -cosTt), (-inc) * ratio);
+    }
+    bool tir = sqrt_arg < 0.0f;                                                   // :137
+    float prob_reflect = Ar * Ar;                                                 // :142
+    bool select_reflect = tir ? true : (s2 < prob_reflect);                       // :144-145
+    V3 chosen = select_reflect ? refl : trans;                                    // :147
+    float pdf_m;
+    if (quirks & PBRT_USQ_UNIT_GGX_PDF) {
+        pdf_m = 1.0f;  // :81-82
+    } else {
+        float c = fabsf(mm.z), a2 = alpha * alpha;
+        float dd = fma_(fma_(a2, 1.0f, -1.0f) * c, c, 1.0f);
+        pdf_m = a2 / (K_PI * dd * dd) * c;
+    }
+    float pdf_reflect = pdf_m / (4.0f * fabsf(cos_wi_m));                         // :154
+    float cos_wo_m = dot(trans, mm);                                              // :155
+    V3 nref = (quirks & PBRT_USQ_MIXED_FRAMES) ? n_sh : v3(0, 0, 1);              // :156-157
+    float abs_n_wi = fabsf(dot(nref, inc));                                       // :156
+    float abs_n_wo = fmaxf(fabsf(dot(nref, trans)), 1e-7f);                       // :157
+    float pdf_trans = pdf_m * (ratio * ratio) * fabsf(cos_wo_m) / (abs_n_wi * abs_n_wo);  // :158
+    UltraOut o;
+    o.chosen = chosen;
+    o.pdf = select_reflect ? pdf_reflect : pdf_trans;                             // :166
+    o.amp = select_reflect ? Ar : At;                                             // :170
+    o.reflect = select_reflect;
+    return o;
+}
+
+// ---- BSDF.sample / eval_pdf, radiance mode (Mitsuba diffuse / conductor / dielectric) -----------
+struct BSample {
+    V3 wo;
+    float pdf;
+    V3 weight;
+    float eta;
+    bool delta, valid;
+    uint32_t lobe;
+};
+
+DEV void bsdf_eval_pdf(const pbrt_material &m, V3 wi, V3 wo, V3 *f, float *pdf) {
+    *f = {0, 0, 0};
+    *pdf = 0.0f;
+    if (m.type == PBRT_MAT_DIFFUSE && wi.z > 0.0f && wo.z > 0.0f) {
+        float c = K_INV_PI * wo.z;
+        *f = v3(m.p[0], m.p[1], m.p[2]) * c;
+        *pdf = c;
+    }
+}
+
+DEV BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, float s1, float s2x,
+                        float s2y) {
+    BSample b;
+    b.valid = false;
+    b.delta = false;
+    b.eta = 1.0f;
+    b.pdf = 0.0f;
+    b.weight = {0, 0, 0};
+    b.wo = {0, 0, 1};
+    b.lobe = 0;
+    const uint32_t type = m.type;
+    if (type == PBRT_MAT_DIFFUSE) {
+        if (!(wi.z > 0.0f)) return b;
+        b.wo = square_to_cosine_hemisphere(s2x, s2y);
+        b.pdf = K_INV_PI * b.wo.z;
+        if (!(b.pdf > 0.0f)) return b;
+        b.weight = v3(m.p[0], m.p[1], m.p[2]);
+        b.valid = true;
+    } else if (type == PBRT_MAT_CONDUCTOR) {
+        if (!(wi.z > 0.0f)) return b;
+        b.wo = {-wi.x, -wi.y, wi.z};
+        b.pdf = 1.0f;
+        b.weight = v3(m.p[0], m.p[1], m.p[2]);
+        b.delta = true;
+        b.valid = true;
+    } else if (type == PBRT_MAT_DIELECTRIC) {
+        float eta = m.p[0];
+        float ci = wi.z;
+        bool outside = ci >= 0.0f;
+        float rcp_eta = 1.0f / eta;
+        float eta_it = outside ? eta : rcp_eta, eta_ti = outside ? rcp_eta : eta;
+        float ct2 = fma_(-fma_(-ci, ci, 1.0f), eta_ti * eta_ti, 1.0f);
+        float cia = fabsf(ci), cta = sqrtf(fmaxf(ct2, 0.0f));
+        float a_s = fma_(-eta_it, cta, cia) / fma_(eta_it, cta, cia);
+        float a_p = fma_(-eta_it, cia, cta) / fma_(eta_it, cia, cta);
+        float r = 0.5f * fma_(a_s, a_s, a_p * a_p);
+        if (eta == 1.0f)
+            r = 0.0f;
+        else if (cia == 0.0f)
+            r = 1.0f;
+        float ct = copysignf(cta, -ci);
+        b.delta = true;
+        b.valid = true;
+        if (s1 <= r) {
+            b.wo = {-wi.x, -wi.y, wi.z};
+            b.pdf = r;
+            b.weight = {1, 1, 1};
+            b.lobe = 0;
+        } else {
+            b.wo = {-eta_ti * wi.x, -eta_ti * wi.y, ct};
+            b.pdf = 1.0f - r;
+            float f2 = eta_ti * eta_ti;
+            b.weight = {f2, f2, f2};
+            b.eta = eta_it;
+            b.lobe = 1;
+        }
+    } else if (type == PBRT_MAT_ULTRA) {
+        UltraOut o = ultra_core(m, quirks, wi, n_geo, n_sh, s1, s2x, s2y);
+        b.wo = to_local(make_frame(n_sh), o.chosen);  // CustomBSDF.py:165
+        b.pdf = o.pdf;
+        b.weight = {o.amp, o.amp, o.amp};
+        b.lobe = o.reflect ? 0u : 1u;
+        b.delta = true;
+        b.valid = true;
+    }
+    return b;
+}
+
+// ---- Emitter.sample_direction (Mitsuba area / point; Scene::sample_emitter_direction) -----------
+struct ESample {
+    V3 q, d;
+    float dist, pdf;
+    V3 weight;
+    bool delta, valid;
+    uint32_t emitter;
+};
+DEV ESample sample_emitter(const DevScene &sc, V3 p, F4 u) {
+    ESample e;
+    e.valid = false;
+    e.delta = false;
+    e.pdf = 0.0f;
+    e.dist = 0.0f;
+    e.weight = {0, 0, 0};
+    e.q = {0, 0, 0};
+    e.d = {0, 0, 0};
+    e.emitter = 0;
+    const uint32_t nE = sc.n_emitters;
+    if (nE == 0) return e;
+    uint32_t ei = min((uint32_t)(u.x * (float)nE), nE - 1);
+    const pbrt_emitter &E = sc.emitters[ei];
+    e.emitter = ei;
+    const float sel = (float)nE;
+    if (E.type == PBRT_EMIT_POINT) {
+        e.q = v3(E.pos[0], E.pos[1], E.pos[2]);
+        V3 dv = e.q - p;
+        float d2 = dot(dv, dv);
+        e.dist = sqrtf(d2);
+        float inv = 1.0f / e.dist;
+        e.d = dv * inv;
+        e.pdf = 1.0f;
+        e.delta = true;
+        float k = (inv * inv) * sel;
+        e.weight = v3(E.radiance[0], E.radiance[1], E.radiance[2]) * k;
+        e.valid = true;
+        return e;
+    }
+    uint32_t k = 0;
+    while (k + 1 < E.count && !(u.y < sc.light_cdf[E.first + k])) ++k;
+    const pbrt_prim &P = sc.prims_by_id[sc.light_prims[E.first + k]];
+    float b1, b2;
+    if (P.type == PBRT_PRIM_TRIANGLE) {
+        float t = sqrtf(fmaxf(1.0f - u.z, 0.0f));
+        b1 = 1.0f - t;
+        b2 = t * u.w;
+    } else {
+        b1 = u.z;
+        b2 = u.w;
+    }
+    e.q = madd(g3(P, 6), b2, madd(g3(P, 3), b1, g3(P, 0)));
+    V3 nl = g3(P, 9);
+    V3 dv = e.q - p;
+    float d2 = dot(dv, dv);
+    e.dist = sqrtf(d2);
+    float inv = 1.0f / e.dist;
+    e.d = dv * inv;
+    float cosl = -dot(nl, e.d);
+    if (!(cosl > 0.0f)) return e;
+    e.pdf = d2 / (cosl * E.area * sel);
+    float w = 1.0f / e.pdf;
+    e.weight = v3(E.radiance[0], E.radiance[1], E.radiance[2]) * w;
+    e.valid = true;
+    return e;
+}
+
+// ---- Sensor.sample_ray: Mitsuba 'perspective' ---------------------------------------------------
+DEV void camera_ray(const pbrt_camera &cam, float sx, float sy, V3 *o, V3 *d, float *tmax) {
+    float tx = cam.tan_half_fov_x;
+    float ty = tx * (float)cam.film_h / (float)cam.film_w;
+    V3 dc = normalize(v3(fma_(-2.0f, sx, 1.0f) * tx, fma_(-2.0f, sy, 1.0f) * ty, 1.0f));
+    V3 dw = normalize(xf_vec(cam.to_world, dc));
+    float inv_z = 1.0f / dc.z;
+    V3 org = {cam.to_world[3], cam.to_world[7], cam.to_world[11]};
+    *o = madd(dw, cam.near_clip * inv_z, org);
+    *d = dw;
+    *tmax = (cam.far_clip - cam.near_clip) * inv_z;
+}

@@ -1,0 +1,385 @@
+// kernels_us.h -- ultrasound-mode wavefront kernels + the batched leaf operators (gfx950).
+//
+// Acquisition = UltraIntegrator.simulate_acquisition_parallel (CustomIntegrator.py:235-405) with
+// P independent Monte-Carlo paths per (angle, element) primary ray.  Same segmented wavefront as
+// radiance mode; state is 11 dwords per slot:
+//   [0..2] origin [3..5] direction [6] amp [7] atten [8] tof [9] geo_len [10] home (uint32)
+// home = ray_id * paths_this_pass + k_local, ray_id = angle * n_elements + element.
+// Echoes are scattered into channel_buf[(angle * n_elements + recv) * T + t_idx] with one f32
+// global atomic per visible bounce (CustomIntegrator.py:351-354).
+#pragma once
+#include "kernels_radiance.h"
+
+#define N_USTATE 11
+
+struct UsArgs {
+    DevScene sc;
+    pbrt_us_params p;
+    const float *in;
+    float *out;
+    const uint32_t *seg_in;
+    uint32_t *seg_out;
+    unsigned long long *stats;
+    float *channel;       // [n_angles * n_elements * time_samples]
+    const float *tx;      // [n_angles * n_elements] transmission delays
+    const float *dir0;    // [n_angles][3] primary directions (world)
+    const float *elem_x;  // [n_elements]
+    float tn[3];          // transducer normal (world)
+    float am, ac, cos_min, katt, two_pi_f, inv_c;
+    uint32_t cap, n_paths, depth, seed;
+    uint32_t ppr_pass, path_first;  // paths per ray in this pass, global index of local path 0
+    uint32_t lds_bytes;
+};
+
+DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // CustomIntegrator.py:289-304
+    V3 w = -sec_dir;
+    float dt = dot(tn, w);
+    float alpha = fabsf(acosf(dt));
+    float mid = (ac - alpha) / (ac - am);
+    return alpha <= am ? 1.0f : (alpha <= ac ? mid : 0.0f);
+}
+
+template <bool FIRST, int ACCEL>
+__global__ __launch_bounds__(SEG) void k_us_bounce(const UsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    __shared__ uint32_t wave_tot[SEG / 64];
+    __shared__ uint32_t wave_seg[SEG / 64];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x, base = seg * SEG;
+    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, (uint32_t)SEG) : 0u) : a.seg_in[seg];
+    if (cnt_in == 0) {
+        if (tid == 0) a.seg_out[seg] = 0;
+        return;
+    }
+    LdsScene ls = {nullptr, nullptr, nullptr};
+    if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
+    const uint32_t cap = a.cap;
+    const bool alive = tid < cnt_in;
+    const uint32_t slot = base + tid;
+    const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
+    bool survive = false, did_seg = false;
+    V3 o, d;
+    float amp, atten, tof, geo_len;
+    uint32_t home = slot;
+    if (alive) {
+        uint32_t ray_id, k;
+        if (FIRST) {
+            ray_id = home / a.ppr_pass;
+            k = a.path_first + (home - ray_id * a.ppr_pass);
+            const uint32_t ang = ray_id / NE, el = ray_id - ang * NE;
+            o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));           // :270,273
+            d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);         // :271,273
+            amp = 1.0f;
+            atten = 1.0f;
+            tof = 0.0f;
+            geo_len = 0.0f;                                                            // :276-279
+        } else {
+            const float *s = a.in + slot;
+            o = {s[0 * cap], s[1 * cap], s[2 * cap]};
+            d = {s[3 * cap], s[4 * cap], s[5 * cap]};
+            amp = s[6 * cap];
+            atten = s[7 * cap];
+            tof = s[8 * cap];
+            geo_len = s[9 * cap];
+            home = __float_as_uint(s[10 * cap]);
+            ray_id = home / a.ppr_pass;
+            k = a.path_first + (home - ray_id * a.ppr_pass);
+        }
+        const uint32_t ang = ray_id / NE;
+        const uint32_t depth = a.depth;
+        const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
+        Hit h;
+        if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h)) {                 // :309-312
+            did_seg = true;
+            const pbrt_prim &P = scene_prim<ACCEL>(a.sc, ls, h.slot);
+            SI si = make_si(P, o, d, h.t, h.u, h.v);
+            const float distance = h.t;                                                // :314
+            geo_len += distance;                                                       // :315
+            const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
+            if (!no_acc) tof += distance * a.inv_c;                                    // :316
+            F4 u = rng4(ray_id, k, depth, a.seed);
+            uint32_t recv = min((uint32_t)(u.x * (float)NE), NE - 1);                  // :319
+            V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f)); // :320-321
+            V3 tv = target - si.p;
+            float dist_recv = sqrtf(dot(tv, tv));
+            V3 sec_dir = tv * (1.0f / dist_recv);                                      // :322
+            Hit hs;
+            bool visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF,
+                                                         &hs);                          // :324-325
+            atten *= expf(a.katt * distance / 8.686f);                                 // :328
+            float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
+            float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;           // :329
+            float phase = a.two_pi_f * total_time;                                     // :330
+            const pbrt_material M = a.sc.mats[P.material];
+            Frame fr = make_frame(si.n);
+            V3 wi = to_local(fr, -d);
+            float a_resp, bpdf;
+            V3 new_dir;
+            bool ok = true;
+            if (M.type == PBRT_MAT_ULTRA) {
+                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, u.w); // :338
+                a_resp = uo.amp;
+                bpdf = uo.pdf;
+                new_dir = to_world(fr, to_local(fr, uo.chosen));                       // CustomBSDF.py:165 + :358
+            } else {
+                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, u.w);
+                ok = bs.valid;
+                a_resp = bs.weight.x;
+                bpdf = bs.pdf;
+                new_dir = to_world(fr, bs.wo);
+            }
+            if (ok) {
+                float cos_theta = dot(si.n, -d);                                       // :340
+                amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                        // :341
+                float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);                 // :286-287,345
+                float fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;        // :345
+                float pressure = atten * amp * fd * sinf(phase);                       // :348
+                float tf = rintf(total_time * a.p.fs);                                 // :351-352
+                if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
+                if (tf >= 0.0f && tf < (float)T && visible)                            // :353
+                    atomicAdd(&a.channel[((size_t)ang * NE + recv) * T + (size_t)tf], pressure);  // :354
+                d = normalize(new_dir);                                                // :358-359
+                o = offset_origin(si.p, si.n, d);
+                float rr_prob = fminf(fabsf(atten * amp), 1.0f);                       // :364
+                bool surv = !(u.w > rr_prob);                                          // :365-366
+                atten /= rr_prob;                                                      // :367
+                bool within = dot(d, tn) >= a.cos_min;                                 // :371
+                survive = within && (geo_len < a.p.max_path_len) && (depth + 1 < a.p.max_depth) && surv;  // :372-376
+            }
+        }
+    }
+    const uint32_t wid = tid >> 6;
+    const unsigned long long bal = __ballot(survive);
+    const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+    const unsigned long long bseg = __ballot(did_seg);
+    if ((tid & 63) == 0) {
+        wave_tot[wid] = (uint32_t)__popcll(bal);
+        wave_seg[wid] = (uint32_t)__popcll(bseg);
+    }
+    __syncthreads();
+    uint32_t off = 0, total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < SEG / 64; ++w) {
+        uint32_t t = wave_tot[w];
+        off += (w < wid) ? t : 0u;
+        total += t;
+    }
+    if (survive) {
+        float *s = a.out + base + off + prefix;
+        s[0 * cap] = o.x;
+        s[1 * cap] = o.y;
+        s[2 * cap] = o.z;
+        s[3 * cap] = d.x;
+        s[4 * cap] = d.y;
+        s[5 * cap] = d.z;
+        s[6 * cap] = amp;
+        s[7 * cap] = atten;
+        s[8 * cap] = tof;
+        s[9 * cap] = geo_len;
+        s[10 * cap] = __uint_as_float(home);
+    }
+    if (tid == 0) {
+        a.seg_out[seg] = total;
+        uint32_t ns = 0;
+        for (uint32_t w = 0; w < SEG / 64; ++w) ns += wave_seg[w];
+        atomicAdd(&a.stats[0], (unsigned long long)ns);
+        atomicAdd(&a.stats[1], (unsigned long long)ns);  // one occlusion ray per shaded segment
+        atomicAdd(&a.stats[2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)], (unsigned long long)cnt_in);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scale(float *buf, size_t n, float s) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) buf[i] *= s;
+}
+
+// ================================================================================================
+// leaf operators: one thread per element, SoA in / SoA out
+// ================================================================================================
+template <int ACCEL>
+__global__ __launch_bounds__(256) void k_ray_intersect(DevScene sc, uint32_t n, const float *o, const float *d,
+                                                       const float *tmax, float *t, uint32_t *prim, float *u, float *v) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LdsScene ls = {nullptr, nullptr, nullptr};
+    Hit h;
+    bool f = scene_intersect<ACCEL, false>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
+                                           tmax[i], &h);
+    t[i] = f ? h.t : K_INF;
+    prim[i] = f ? h.prim : 0xffffffffu;
+    u[i] = f ? h.u : 0.0f;
+    v[i] = f ? h.v : 0.0f;
+}
+
+template <int ACCEL>
+__global__ __launch_bounds__(256) void k_ray_test(DevScene sc, uint32_t n, const float *o, const float *d,
+                                                  const float *tmax, uint8_t *hit) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LdsScene ls = {nullptr, nullptr, nullptr};
+    Hit h;
+    hit[i] = scene_intersect<ACCEL, true>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
+                                          tmax[i], &h)
+                 ? 1
+                 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_bsdf_sample(pbrt_material m, uint32_t quirks, uint32_t n, const float *wi,
+                                                     const float *ng, const float *ns, const float *s1, const float *s2,
+                                                     float *wo, float *pdf, float *weight, uint32_t *sampled) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 g = ng ? v3(ng[i], ng[n + i], ng[2 * n + i]) : v3(0, 0, 1);
+    V3 s = ns ? v3(ns[i], ns[n + i], ns[2 * n + i]) : v3(0, 0, 1);
+    BSample b = bsdf_sample(m, quirks, v3(wi[i], wi[n + i], wi[2 * n + i]), g, s, s1[i], s2[i], s2[n + i]);
+    wo[i] = b.wo.x;
+    wo[n + i] = b.wo.y;
+    wo[2 * n + i] = b.wo.z;
+    pdf[i] = b.pdf;
+    weight[i] = b.weight.x;
+    weight[n + i] = b.weight.y;
+    weight[2 * n + i] = b.weight.z;
+    sampled[i] = b.valid ? b.lobe : 0xffffffffu;
+}
+
+__global__ __launch_bounds__(256) void k_bsdf_eval_pdf(pbrt_material m, uint32_t n, const float *wi, const float *wo,
+                                                       float *f, float *pdf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 fv;
+    float p;
+    bsdf_eval_pdf(m, v3(wi[i], wi[n + i], wi[2 * n + i]), v3(wo[i], wo[n + i], wo[2 * n + i]), &fv, &p);
+    f[i] = fv.x;
+    f[n + i] = fv.y;
+    f[2 * n + i] = fv.z;
+    pdf[i] = p;
+}
+
+__global__ __launch_bounds__(256) void k_emitter_sample(DevScene sc, uint32_t n, const float *p, const float *u, float *d,
+                                                        float *dist, float *pdf, float *weight, float *q,
+                                                        uint32_t *emitter) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ESample e = sample_emitter(sc, v3(p[i], p[n + i], p[2 * n + i]), F4{u[i], u[n + i], u[2 * n + i], u[3 * n + i]});
+    d[i] = e.d.x;
+    d[n + i] = e.d.y;
+    d[2 * n + i] = e.d.z;
+    q[i] = e.q.x;
+    q[n + i] = e.q.y;
+    q[2 * n + i] = e.q.z;
+    dist[i] = e.dist;
+    pdf[i] = e.valid ? e.pdf : 0.0f;
+    weight[i] = e.valid ? e.weight.x : 0.0f;
+    weight[n + i] = e.valid ? e.weight.y : 0.0f;
+    weight[2 * n + i] = e.valid ? e.weight.z : 0.0f;
+    emitter[i] = e.emitter;
+}
+
+__global__ __launch_bounds__(256) void k_sensor_sample_ray(pbrt_camera cam, uint32_t n, const float *pos, float *o,
+                                                           float *d, float *tmax) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    V3 oo, dd;
+    float tm;
+    camera_ray(cam, pos[i], pos[n + i], &oo, &dd, &tm);
+    o[i] = oo.x;
+    o[n + i] = oo.y;
+    o[2 * n + i] = oo.z;
+    d[i] = dd.x;
+    d[n + i] = dd.y;
+    d[2 * n + i] = dd.z;
+    tmax[i] = tm;
+}
+
+// UltraSensor.sample_ray (bytecode-only class)
+__global__ __launch_bounds__(256) void k_us_sensor_sample_ray(pbrt_us_sensor s, int hemi, uint32_t n, const float *time,
+                                                              const float *wl, const float *pos, const float *ap,
+                                                              float *o, float *d, float *weight) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float N = (float)s.num_elements;
+    float px = pos[i], py = pos[n + i], ax = ap[i], ay = ap[n + i];
+    float ei = fminf(floorf(px * N), N - 1.0f);
+    float ex, ez;
+    if (__builtin_isinf(s.radius)) {
+        ex = fma_(ei, s.pitch, -((N - 1.0f) * s.pitch) / 2.0f);
+        ez = 0.0f;
+    } else {
+        float th = (ei - N / 2.0f) * (s.pitch / s.radius);
+        ex = s.radius * sinf(th);
+        ez = s.radius * (1.0f - cosf(th));
+    }
+    float offx = (ax - 0.5f) * s.element_width, offy = (ay - 0.5f) * s.element_height;
+    V3 ol = {ex + offx, offy, ez};
+    V3 dl;
+    if (hemi) {
+        dl = square_to_uniform_hemisphere(ax, ay);
+    } else {
+        float phi = 2.0f * K_PI * py, ct = wl[i];
+        float st = sqrtf(fmaxf(0.0f, 1.0f - ct * ct));
+        dl = {st * cosf(phi), st * sinf(phi), ct};
+    }
+    V3 ow = xf_point(s.to_world, ol);
+    V3 dw = normalize(xf_vec(s.to_world, dl));
+    float dweight = fabsf(dl.z) * s.directivity;
+    weight[i] = cosf(2.0f * K_PI * s.center_frequency * time[i]) * dweight;
+    o[i] = ow.x;
+    o[n + i] = ow.y;
+    o[2 * n + i] = ow.z;
+    d[i] = dw.x;
+    d[n + i] = dw.y;
+    d[2 * n + i] = dw.z;
+}
+
+// CustomEmitter.sample_position + sample_ray (CustomEmmitter.py:30-107)
+__global__ __launch_bounds__(256) void k_us_emitter_sample_ray(pbrt_us_emitter e, uint32_t n, const float *time,
+                                                               const float *s1, const float *s2, const float *s3, float *o,
+                                                               float *d, float *ray_time, float *weight, float *pdf_pos) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float N = (float)e.number_of_elements;
+    const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
+    float idx = fminf(floorf(s1[i] * N), N - 1.0f);                                         // :56-57
+    V3 c, nrm;
+    if (e.radius == 0.0f) {                                                                 // :33-38
+        float lo = -(N - 1.0f) / 2.0f * e.pitch, hi = (N - 1.0f) / 2.0f * e.pitch;
+        float x = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {x, 0.0f, 0.0f};
+        nrm = {0.0f, 0.0f, 1.0f};
+    } else {                                                                                // :41-47
+        float span = e.opening_angle * (K_PI / 180.0f);
+        float lo = -span / 2.0f, hi = span / 2.0f;
+        float th = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
+        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
+    }
+    float dx = (s2[i] - 0.5f) * e.element_width, dy = (s2[n + i] - 0.5f) * e.element_height;  // :64-65
+    V3 pos = c + v3(dx, dy, 0.0f);                                                          // :68
+    pdf_pos[i] = 1.0f / (N * e.element_width * e.element_height);                           // :77
+    float pmin = e.steering_angle_min * (K_PI / 180.0f), pmax = e.steering_angle_max * (K_PI / 180.0f);
+    float psi = fma_(s3[i], pmax - pmin, pmin);                                             // :85-87
+    V3 dir = {sinf(psi), 0.0f, cosf(psi)};                                                  // :90
+    float delay = -(pos.x * sinf(psi)) / e.speed_of_sound;                                  // :93
+    ray_time[i] = time[i] + delay;                                                          // :94
+    float fd = fmaxf(0.0f, dot(dir, nrm));                                                  // :97
+    weight[i] = fd / total_rays;                                                            // :98
+    o[i] = pos.x;
+    o[n + i] = pos.y;
+    o[2 * n + i] = pos.z;
+    d[i] = dir.x;
+    d[n + i] = dir.y;
+    d[2 * n + i] = dir.z;
+}
+
+// CustomSensor.put_data (CustomSensor.py:29-59)
+__global__ __launch_bounds__(256) void k_us_put_data(pbrt_us_receiver r, uint32_t n, const float *ox, const float *time,
+                                                     const float *d, const float *amplitude, float *buf) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double idx = rint((double)ox[i] / (double)r.pitch + (double)r.number_of_elements / 2.0);  // :36
+    double ti = rint((double)time[i] * (double)r.sample_rate);                                // :43
+    V3 dir = normalize(-v3(d[i], d[n + i], d[2 * n + i]));                                    // :46
+    float gain = fmaxf(0.0f, dot(dir, v3(0, 0, 1)));                                          // :51
+    float amp = amplitude[i] * gain;                                                          // :53
+    if (idx >= 0 && idx < (double)r.number_of_elements && ti >= 0 && ti < (double)r.time_samples)  // :58
+        atomicAdd(&buf[(size_t)idx * r.time_samples + (size_t)ti], amp);                      // :59
+}

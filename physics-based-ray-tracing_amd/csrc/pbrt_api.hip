@@ -1,0 +1,946 @@
+// pbrt_api.hip -- host side of libpbrt_hip.so: the C-ABI of include/pbrt_hip.h.
+// One pbrt_ctx per device (HIP stream, grow-only workspace in HBM, last-error string); scenes are
+// uploaded once and stay resident; every entry point is synchronous on return.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "kernels_us.h"
+
+static std::string g_ctxless_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct pbrt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    pbrt_stats stats{};
+    std::map<std::string, DevBuf> ws;  // grow-only workspace
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t lds_limit = 0;
+
+    int fail(int code, const char *fmt, ...) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+    // returns nullptr on failure (err set)
+    void *buf(const char *name, size_t bytes) {
+        DevBuf &b = ws[name];
+        if (b.bytes >= bytes && b.p) return b.p;
+        if (b.p) (void)hipFree(b.p);
+        b.p = nullptr;
+        b.bytes = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            fail(PBRT_E_NOMEM, "hipMalloc(%zu) for %s: %s", want, name, hipGetErrorString(e));
+            b.p = nullptr;
+            return nullptr;
+        }
+        b.bytes = want;
+        return b.p;
+    }
+    hipEvent_t event(size_t i) {
+        while (ev_pool.size() <= i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            ev_pool.push_back(e);
+        }
+        return ev_pool[i];
+    }
+};
+
+struct pbrt_scene {
+    pbrt_ctx *ctx = nullptr;
+    DevScene ds{};
+    int accel_kernel = ACCEL_K_BRUTE;
+    uint32_t lds_bytes = 0;
+    std::vector<void *> allocs;
+    pbrt_material *d_mats = nullptr;
+    uint32_t n_mats = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return (ctx)->fail(PBRT_E_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+#define NEED(ctx, cond)                                                        \
+    do {                                                                       \
+        if (!(cond)) return (ctx)->fail(PBRT_E_INVALID, "invalid argument: %s", #cond); \
+    } while (0)
+
+template <typename T>
+static int upload(pbrt_scene *s, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(n * sizeof(T), 16);
+    HIPCHK(s->ctx, hipMalloc(&p, bytes));
+    s->allocs.push_back(p);
+    if (n) HIPCHK(s->ctx, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    return PBRT_OK;
+}
+
+static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+extern "C" {
+
+int pbrt_abi_version(void) { return PBRT_ABI_VERSION; }
+
+int pbrt_ctx_create(int device, pbrt_ctx **out) {
+    if (!out) {
+        g_ctxless_error = "pbrt_ctx_create: out is NULL";
+        return PBRT_E_INVALID;
+    }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) {
+        g_ctxless_error = std::string("no HIP device visible: ") + hipGetErrorString(e) +
+                          " (the ray-transport hot path has no CPU fallback)";
+        return PBRT_E_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        g_ctxless_error = "device index out of range";
+        return PBRT_E_INVALID;
+    }
+    pbrt_ctx *c = new pbrt_ctx();
+    c->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        g_ctxless_error = std::string("device init: ") + hipGetErrorString(e);
+        delete c;
+        return PBRT_E_DEVICE;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->lds_limit = (uint32_t)prop.sharedMemPerBlock;
+    *out = c;
+    return PBRT_OK;
+}
+
+int pbrt_ctx_destroy(pbrt_ctx *c) {
+    if (!c) return PBRT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &kv : c->ws)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return PBRT_OK;
+}
+
+const char *pbrt_last_error(pbrt_ctx *c) { return c ? c->err.c_str() : g_ctxless_error.c_str(); }
+
+int pbrt_get_stats(pbrt_ctx *c, pbrt_stats *out) {
+    if (!c || !out) return PBRT_E_INVALID;
+    *out = c->stats;
+    return PBRT_OK;
+}
+
+int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
+    if (!c) return PBRT_E_INVALID;
+    NEED(c, d && out);
+    NEED(c, d->n_prims > 0 && d->prims && d->n_materials > 0 && d->materials);
+    NEED(c, d->n_emitters == 0 || d->emitters);
+    NEED(c, d->n_light_prims == 0 || (d->light_prims && d->light_cdf));
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const pbrt_prim &p = d->prims[i];
+        if (p.type > PBRT_PRIM_PARALLELOGRAM)
+            return c->fail(PBRT_E_UNSUPPORTED, "primitive %u: type %u is not supported (cone: SURVEY 8 f-4)", i, p.type);
+        if (p.material >= d->n_materials) return c->fail(PBRT_E_INVALID, "primitive %u: material out of range", i);
+        if (p.emitter >= 0 && (uint32_t)p.emitter >= d->n_emitters)
+            return c->fail(PBRT_E_INVALID, "primitive %u: emitter out of range", i);
+    }
+    for (uint32_t i = 0; i < d->n_emitters; ++i) {
+        const pbrt_emitter &e = d->emitters[i];
+        if (e.type == PBRT_EMIT_AREA) {
+            if (e.count == 0 || e.first + e.count > d->n_light_prims)
+                return c->fail(PBRT_E_INVALID, "emitter %u: light primitive range out of bounds", i);
+            for (uint32_t k = 0; k < e.count; ++k) {
+                uint32_t pi = d->light_prims[e.first + k];
+                if (pi >= d->n_prims || d->prims[pi].type == PBRT_PRIM_SPHERE)
+                    return c->fail(PBRT_E_UNSUPPORTED, "emitter %u: area lights need triangle/parallelogram primitives", i);
+            }
+        } else if (e.type != PBRT_EMIT_POINT) {
+            return c->fail(PBRT_E_INVALID, "emitter %u: unknown type", i);
+        }
+    }
+    HIPCHK(c, hipSetDevice(c->device));
+    pbrt_scene *s = new pbrt_scene();
+    s->ctx = c;
+    int rc;
+    const pbrt_prim *d_prims_by_id = nullptr;
+#define UP(call)               \
+    if ((rc = (call)) != 0) {  \
+        pbrt_scene_destroy(s); \
+        return rc;             \
+    }
+    UP(upload(s, d->prims, d->n_prims, &d_prims_by_id));
+    s->ds.prims_by_id = d_prims_by_id;
+    s->ds.n_prims = d->n_prims;
+    const pbrt_material *dm = nullptr;
+    UP(upload(s, d->materials, d->n_materials, &dm));
+    s->ds.mats = dm;
+    s->d_mats = const_cast<pbrt_material *>(dm);
+    s->n_mats = s->ds.n_mats = d->n_materials;
+    UP(upload(s, d->emitters, d->n_emitters, &s->ds.emitters));
+    s->ds.n_emitters = d->n_emitters;
+    UP(upload(s, d->light_prims, d->n_light_prims, &s->ds.light_prims));
+    UP(upload(s, d->light_cdf, d->n_light_prims, &s->ds.light_cdf));
+    const bool want_bvh = d->accel == PBRT_ACCEL_BVH || (d->accel == PBRT_ACCEL_AUTO && d->n_prims > 32);
+    if (!want_bvh) {
+        s->ds.prims = d_prims_by_id;
+        s->ds.prim_ids = nullptr;
+        s->ds.nodes = nullptr;
+        s->ds.n_nodes = 0;
+        s->accel_kernel = ACCEL_K_BRUTE;
+    } else {
+        HostBvh bvh;
+        build_bvh(d->prims, d->n_prims, &bvh);
+        if (bvh.max_depth > 30) {
+            pbrt_scene_destroy(s);
+            return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
+        }
+        std::vector<pbrt_prim> ordered(d->n_prims);
+        for (uint32_t k = 0; k < d->n_prims; ++k) ordered[k] = d->prims[bvh.order[k]];
+        UP(upload(s, ordered.data(), ordered.size(), &s->ds.prims));
+        UP(upload(s, bvh.order.data(), bvh.order.size(), &s->ds.prim_ids));
+        const DevNode *dn = nullptr;
+        UP(upload(s, reinterpret_cast<const DevNode *>(bvh.nodes.data()), bvh.nodes.size(), &dn));
+        s->ds.nodes = dn;
+        s->ds.n_nodes = (uint32_t)bvh.nodes.size();
+        size_t lds = bvh.nodes.size() * sizeof(DevNode) + (size_t)d->n_prims * (sizeof(pbrt_prim) + 4);
+        // static LDS of the bounce kernels: 3 * SEG/64 dwords; keep 1 KiB of slack
+        if (c->lds_limit && lds + 1024 <= c->lds_limit) {
+            s->accel_kernel = ACCEL_K_BVH_LDS;
+            s->lds_bytes = (uint32_t)((lds + 15) & ~size_t(15));
+        } else {
+            s->accel_kernel = ACCEL_K_BVH_GLOBAL;
+        }
+    }
+#undef UP
+    *out = s;
+    return PBRT_OK;
+}
+
+int pbrt_scene_update_material(pbrt_scene *s, uint32_t index, const pbrt_material *m) {
+    if (!s) return PBRT_E_INVALID;
+    pbrt_ctx *c = s->ctx;
+    NEED(c, m && index < s->n_mats);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpy(s->d_mats + index, m, sizeof *m, hipMemcpyHostToDevice));
+    return PBRT_OK;
+}
+
+int pbrt_scene_destroy(pbrt_scene *s) {
+    if (!s) return PBRT_OK;
+    (void)hipSetDevice(s->ctx->device);
+    for (void *p : s->allocs) (void)hipFree(p);
+    delete s;
+    return PBRT_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// radiance mode driver
+// ------------------------------------------------------------------------------------------------
+template <bool FIRST>
+static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg) {
+    hipStream_t st = s->ctx->stream;
+    switch (s->accel_kernel) {
+        case ACCEL_K_BRUTE:
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        case ACCEL_K_BVH_GLOBAL:
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        default:
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG), s->lds_bytes, st, a);
+            break;
+    }
+}
+
+static int set_lds_attr(pbrt_scene *s) {
+    if (s->accel_kernel != ACCEL_K_BVH_LDS) return PBRT_OK;
+    pbrt_ctx *c = s->ctx;
+    int bytes = (int)s->lds_bytes;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, ACCEL_K_BVH_LDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, ACCEL_K_BVH_LDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<true, ACCEL_K_BVH_LDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<false, ACCEL_K_BVH_LDS>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    return PBRT_OK;
+}
+
+// Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
+static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, uint64_t samples, uint64_t film_px,
+                                 uint32_t passes, uint64_t *total, uint64_t *bounce) {
+    uint64_t b = 0;
+    for (uint32_t d = 0; d < nd; ++d) {
+        uint64_t in = live[d], next = (d + 1 < nd) ? live[d + 1] : 0;
+        if (d > 0) b += in * (N_STATE * 4);  // state read
+        b += next * (N_STATE * 4);            // compacted survivors written
+        b += (in - next) * 12;                // radiance of the paths that ended
+    }
+    *bounce = b;
+    *total = b + samples * 12 /* film gather reads Lhome once */ + film_px * 32ull * passes /* accumulator RMW */ +
+             film_px * 28 /* resolve */;
+}
+
+static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
+    pbrt_ctx *c = s->ctx;
+    NEED(c, cam && f && d_out);
+    const uint32_t W = cam->film_w, H = cam->film_h;
+    NEED(c, W > 0 && H > 0 && f->crop_w > 0 && f->crop_h > 0);
+    NEED(c, (uint64_t)f->crop_x + f->crop_w <= W && (uint64_t)f->crop_y + f->crop_h <= H);
+    NEED(c, f->spp > 0 && f->max_depth > 0 && f->filter <= PBRT_FILTER_GAUSSIAN);
+    NEED(c, (uint64_t)W * H <= 0xffffffffull);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_lds_attr(s);
+    if (rc) return rc;
+    const uint32_t R = f->filter == PBRT_FILTER_BOX ? 0 : (f->filter == PBRT_FILTER_TENT ? 1 : 2);
+    const uint32_t rx0 = f->crop_x > R ? f->crop_x - R : 0, ry0 = f->crop_y > R ? f->crop_y - R : 0;
+    const uint32_t rx1 = std::min(f->crop_x + f->crop_w + R, W), ry1 = std::min(f->crop_y + f->crop_h + R, H);
+    const uint32_t rw = rx1 - rx0, rh = ry1 - ry0;
+    const uint64_t npix_r = (uint64_t)rw * rh;
+    const uint64_t film_px = (uint64_t)f->crop_w * f->crop_h;
+    uint64_t pass_paths = f->pass_paths ? f->pass_paths : (8u << 20);
+    uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
+    NEED(c, npix_r * s_pass < 0xfffffc00ull);
+    const uint32_t cap = div_up(npix_r * s_pass, SEG) * SEG;
+    const uint32_t nseg = cap / SEG;
+    float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
+    float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    float *acc = (float *)c->buf("film_acc", film_px * 16);
+    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemsetAsync(acc, 0, film_px * 16, st));
+    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    size_t n_ev = 0;
+    uint32_t passes = 0, launches = 0;
+    for (uint32_t s0 = 0; s0 < f->spp; s0 += s_pass, ++passes) {
+        const uint32_t sc = std::min(s_pass, f->spp - s0);
+        RadArgs a{};
+        a.sc = s->ds;
+        a.cam = *cam;
+        a.Lhome = Lhome;
+        a.stats = dstats;
+        a.cap = cap;
+        a.n_paths = (uint32_t)(npix_r * sc);
+        a.max_depth = f->max_depth;
+        a.rr_depth = f->rr_depth;
+        a.seed = f->seed;
+        a.key_mode = 0;
+        a.rx0 = rx0;
+        a.ry0 = ry0;
+        a.rw = rw;
+        a.npix_r = (uint32_t)npix_r;
+        a.s_first = f->sample_offset + s0;
+        a.film_w = W;
+        a.film_h = H;
+        a.lds_bytes = s->lds_bytes;
+        const uint32_t nseg_pass = div_up(a.n_paths, SEG);
+        float *in = stA, *out = stB;
+        uint32_t *sin = segA, *sout = segB;
+        for (uint32_t depth = 0; depth < f->max_depth; ++depth) {
+            a.depth = depth;
+            a.in = in;
+            a.out = out;
+            a.seg_in = sin;
+            a.seg_out = sout;
+            hipEvent_t e0 = c->event(n_ev), e1 = c->event(n_ev + 1);
+            if (!e0 || !e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+            n_ev += 2;
+            HIPCHK(c, hipEventRecord(e0, st));
+            if (depth == 0)
+                launch_bounce<true>(s, a, nseg_pass);
+            else
+                launch_bounce<false>(s, a, nseg_pass);
+            HIPCHK(c, hipEventRecord(e1, st));
+            HIPCHK(c, hipGetLastError());
+            ++launches;
+            std::swap(in, out);
+            std::swap(sin, sout);
+            // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces
+            if (f->max_depth > 32 && (depth & 7) == 7) {
+                std::vector<uint32_t> cnt(nseg_pass);
+                HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nseg_pass * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(c, hipStreamSynchronize(st));
+                uint64_t live = 0;
+                for (uint32_t v : cnt) live += v;
+                if (live == 0) break;
+            }
+        }
+        FilmArgs fa{};
+        fa.Lhome = Lhome;
+        fa.acc = acc;
+        fa.cap = cap;
+        fa.cx0 = f->crop_x;
+        fa.cy0 = f->crop_y;
+        fa.cw = f->crop_w;
+        fa.ch = f->crop_h;
+        fa.rx0 = rx0;
+        fa.ry0 = ry0;
+        fa.rw = rw;
+        fa.rh = rh;
+        fa.npix_r = (uint32_t)npix_r;
+        fa.s_first = a.s_first;
+        fa.s_count = sc;
+        fa.film_w = W;
+        fa.film_h = H;
+        fa.filter = f->filter;
+        fa.seed = f->seed;
+        hipLaunchKernelGGL(k_film_accum, dim3(div_up(film_px, 256)), dim3(256), 0, st, fa);
+        HIPCHK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_film_resolve, dim3(div_up(film_px, 256)), dim3(256), 0, st, acc, (float *)d_out, (uint32_t)film_px,
+                       (uint32_t)((f->flags & PBRT_FILM_RAW_ACCUM) ? 1 : 0));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    unsigned long long hstats[2 + MAX_DEPTH_STATS];
+    HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double bounce_ms = 0.0;
+    for (size_t i = 0; i + 1 < n_ev; i += 2) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1]));
+        bounce_ms += t;
+    }
+    pbrt_stats &S = c->stats;
+    S = pbrt_stats{};
+    S.samples = npix_r * f->spp;
+    S.segments = hstats[0];
+    S.shadow_rays = hstats[1];
+    S.kernel_ms = ms;
+    S.bounce_ms = bounce_ms;
+    S.bounce_launches = launches;
+    S.passes = passes;
+    uint64_t tot, bb;
+    radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, &tot, &bb);
+    S.model_bytes = tot;
+    S.bounce_model_bytes = bb;
+    return PBRT_OK;
+}
+
+extern "C" {
+
+int pbrt_render_radiance_dev(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
+    if (!s) return PBRT_E_INVALID;
+    return render_impl(s, cam, f, d_out);
+}
+
+int pbrt_render_radiance(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, float *out) {
+    if (!s) return PBRT_E_INVALID;
+    pbrt_ctx *c = s->ctx;
+    NEED(c, cam && f && out);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)f->crop_w * f->crop_h * ((f->flags & PBRT_FILM_RAW_ACCUM) ? 4 : 3);
+    void *d = c->buf("film_out", n * 4);
+    if (!d) return PBRT_E_NOMEM;
+    int rc = render_impl(s, cam, f, d);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(out, d, n * 4, hipMemcpyDeviceToHost));
+    return PBRT_OK;
+}
+
+int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const float *d, const float *tmax,
+                           uint32_t index_offset, uint32_t sample_index, uint32_t seed, uint32_t max_depth,
+                           uint32_t rr_depth, float *rgb) {
+    if (!s) return PBRT_E_INVALID;
+    pbrt_ctx *c = s->ctx;
+    NEED(c, o && d && tmax && rgb && max_depth > 0);
+    if (n == 0) return PBRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_lds_attr(s);
+    if (rc) return rc;
+    const uint32_t cap = div_up(n, SEG) * SEG, nseg = cap / SEG;
+    float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
+    float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
+    if (!stA || !stB || !Lhome || !segA || !segB || !dstats || !io) return PBRT_E_NOMEM;
+    hipStream_t st = c->stream;
+    HIPCHK(c, hipMemcpyAsync(io, o, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(io + 3 * (size_t)n, d, (size_t)n * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 12, st));
+    hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, n, io,
+                       io + 3 * (size_t)n, io + 6 * (size_t)n);
+    RadArgs a{};
+    a.sc = s->ds;
+    a.Lhome = Lhome;
+    a.stats = dstats;
+    a.cap = cap;
+    a.n_paths = n;
+    a.max_depth = max_depth;
+    a.rr_depth = rr_depth;
+    a.seed = seed;
+    a.key_mode = 1;
+    a.npix_r = 1;
+    a.rw = 1;
+    a.index_offset = index_offset;
+    a.sample_index = sample_index;
+    a.lds_bytes = s->lds_bytes;
+    float *in = stA, *out = stB;
+    uint32_t *sin = segA, *sout = segB;
+    for (uint32_t depth = 0; depth < max_depth; ++depth) {
+        a.depth = depth;
+        a.in = in;
+        a.out = out;
+        a.seg_in = sin;
+        a.seg_out = sout;
+        launch_bounce<false>(s, a, nseg);
+        HIPCHK(c, hipGetLastError());
+        std::swap(in, out);
+        std::swap(sin, sout);
+        if (max_depth > 32 && (depth & 7) == 7) {
+            std::vector<uint32_t> cnt(nseg);
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            uint64_t live = 0;
+            for (uint32_t v : cnt) live += v;
+            if (live == 0) break;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int k = 0; k < 3; ++k)
+        HIPCHK(c, hipMemcpy(rgb + (size_t)k * n, Lhome + (size_t)k * cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return PBRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ultrasound mode driver
+// ------------------------------------------------------------------------------------------------
+static inline float host_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx) {
+    if (!p || !tx || p->n_angles > PBRT_US_MAX_ANGLES || p->n_angles == 0 || p->n_elements == 0) return PBRT_E_INVALID;
+    for (uint32_t a = 0; a < p->n_angles; ++a) {
+        double ar = (double)p->angles_deg[a] * (M_PI / 180.0);  // np.deg2rad, CustomIntegrator.py:247
+        for (uint32_t e = 0; e < p->n_elements; ++e) {
+            // :248 float32 elem_x = pitch * (arange_f32 - (N-1)/2); :254,257 tx = f32(elem_x * sin(a) / c)
+            float ex = (float)((double)p->pitch * ((double)(float)e - ((double)p->n_elements - 1.0) / 2.0));
+            tx[a * p->n_elements + e] = (float)(((double)ex * std::sin(ar)) / (double)p->sound_speed);
+        }
+    }
+    return PBRT_OK;
+}
+
+}  // extern "C"
+
+template <bool FIRST>
+static void launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
+    hipStream_t st = s->ctx->stream;
+    switch (s->accel_kernel) {
+        case ACCEL_K_BRUTE:
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        case ACCEL_K_BVH_GLOBAL:
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        default:
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG), s->lds_bytes, st, a);
+            break;
+    }
+}
+
+extern "C" {
+
+static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
+                   uint32_t norm_paths, float *d_channel, float *tx_host) {
+    pbrt_ctx *c = s->ctx;
+    NEED(c, p && d_channel);
+    NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
+    NEED(c, p->max_depth > 0 && ppr > 0 && p->sound_speed > 0 && p->fs > 0);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = set_lds_attr(s);
+    if (rc) return rc;
+    const uint32_t NA = p->n_angles, NE = p->n_elements, T = p->time_samples;
+    const uint32_t n_rays = NA * NE;
+    std::vector<float> tx(n_rays), dir0(3 * NA), ex(NE);
+    pbrt_us_tx_delays(p, tx.data());
+    if (tx_host) std::memcpy(tx_host, tx.data(), tx.size() * 4);
+    const float *M = p->sensor_to_world;
+    auto xfv = [&](float x, float y, float z, float *o) {
+        o[0] = host_fma(M[0], x, host_fma(M[1], y, M[2] * z));
+        o[1] = host_fma(M[4], x, host_fma(M[5], y, M[6] * z));
+        o[2] = host_fma(M[8], x, host_fma(M[9], y, M[10] * z));
+    };
+    auto nrm = [&](float *v) {
+        float inv = 1.0f / std::sqrt(host_fma(v[0], v[0], host_fma(v[1], v[1], v[2] * v[2])));
+        v[0] *= inv;
+        v[1] *= inv;
+        v[2] *= inv;
+    };
+    for (uint32_t a = 0; a < NA; ++a) {  // CustomIntegrator.py:265,271,273
+        float ar = (float)((double)p->angles_deg[a] * (M_PI / 180.0));
+        xfv(sinf(ar), 0.0f, cosf(ar), &dir0[3 * a]);
+        nrm(&dir0[3 * a]);
+    }
+    for (uint32_t e = 0; e < NE; ++e)
+        ex[e] = (float)((double)p->pitch * ((double)(float)e - ((double)NE - 1.0) / 2.0));  // :248
+    const uint64_t pass_paths = 8u << 20;
+    uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
+    NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
+    const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, SEG) * SEG, nseg = cap / SEG;
+    float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
+    float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
+    if (!stA || !stB || !segA || !segB || !dstats || !tabs) return PBRT_E_NOMEM;
+    hipStream_t st = c->stream;
+    float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
+    HIPCHK(c, hipMemcpyAsync(d_tx, tx.data(), (size_t)n_rays * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_dir, dir0.data(), (size_t)NA * 12, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_ex, ex.data(), (size_t)NE * 4, hipMemcpyHostToDevice, st));
+    const size_t nchan = (size_t)n_rays * T;
+    HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
+    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipEventRecord(c->ev0, st));
+    UsArgs a{};
+    a.sc = s->ds;
+    a.p = *p;
+    a.stats = dstats;
+    a.channel = d_channel;
+    a.tx = d_tx;
+    a.dir0 = d_dir;
+    a.elem_x = d_ex;
+    float tn[3];
+    xfv(0.0f, 0.0f, 1.0f, tn);
+    nrm(tn);
+    a.tn[0] = tn[0];
+    a.tn[1] = tn[1];
+    a.tn[2] = tn[2];
+    a.am = p->main_beam_angle * (K_PI / 180.0f);
+    a.ac = p->cutoff_angle * (K_PI / 180.0f);
+    a.cos_min = cosf(a.ac);                                                           // :370
+    a.katt = (float)(-(double)p->attenuation * (double)p->frequency * 1e-6);          // :328
+    a.two_pi_f = (float)(2.0 * M_PI * (double)p->frequency);                          // :330
+    a.inv_c = 1.0f / p->sound_speed;
+    a.cap = cap;
+    a.seed = seed;
+    a.lds_bytes = s->lds_bytes;
+    size_t n_ev = 0;
+    uint32_t passes = 0, launches = 0;
+    for (uint32_t k0 = 0; k0 < ppr; k0 += ppr_pass, ++passes) {
+        const uint32_t kc = std::min(ppr_pass, ppr - k0);
+        a.ppr_pass = kc;
+        a.path_first = path_offset + k0;
+        a.n_paths = n_rays * kc;
+        const uint32_t nseg_pass = div_up(a.n_paths, SEG);
+        float *in = stA, *out = stB;
+        uint32_t *sin = segA, *sout = segB;
+        for (uint32_t depth = 0; depth < p->max_depth; ++depth) {
+            a.depth = depth;
+            a.in = in;
+            a.out = out;
+            a.seg_in = sin;
+            a.seg_out = sout;
+            hipEvent_t e0 = c->event(n_ev), e1 = c->event(n_ev + 1);
+            if (!e0 || !e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+            n_ev += 2;
+            HIPCHK(c, hipEventRecord(e0, st));
+            if (depth == 0)
+                launch_us<true>(s, a, nseg_pass);
+            else
+                launch_us<false>(s, a, nseg_pass);
+            HIPCHK(c, hipEventRecord(e1, st));
+            HIPCHK(c, hipGetLastError());
+            ++launches;
+            std::swap(in, out);
+            std::swap(sin, sout);
+        }
+    }
+    const float inv_norm = 1.0f / (float)(norm_paths ? norm_paths : 1);
+    hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev1, st));
+    unsigned long long hstats[2 + MAX_DEPTH_STATS];
+    HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    float ms = 0.0f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    double bounce_ms = 0.0;
+    for (size_t i = 0; i + 1 < n_ev; i += 2) {
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1]));
+        bounce_ms += t;
+    }
+    pbrt_stats &S = c->stats;
+    S = pbrt_stats{};
+    S.samples = (uint64_t)n_rays * ppr;
+    S.segments = hstats[0];
+    S.shadow_rays = hstats[1];
+    S.kernel_ms = ms;
+    S.bounce_ms = bounce_ms;
+    S.bounce_launches = launches;
+    S.passes = passes;
+    uint64_t bb = 0;
+    for (uint32_t d = 0; d < MAX_DEPTH_STATS; ++d) {
+        uint64_t in = hstats[2 + d], next = d + 1 < MAX_DEPTH_STATS ? hstats[2 + d + 1] : 0;
+        if (d > 0) bb += in * (N_USTATE * 4);
+        bb += next * (N_USTATE * 4);
+    }
+    bb += hstats[0] * 8;  // one f32 atomic (read-modify-write) per shaded segment, upper bound
+    S.bounce_model_bytes = bb;
+    S.model_bytes = bb + nchan * 12;  // clear + scale pass over the channel buffer
+    return PBRT_OK;
+}
+
+int pbrt_us_acquire_dev(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
+                        uint32_t norm_paths, void *d_channel, float *tx) {
+    if (!s) return PBRT_E_INVALID;
+    return us_impl(s, p, seed, ppr, path_offset, norm_paths, (float *)d_channel, tx);
+}
+
+int pbrt_us_acquire(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
+                    uint32_t norm_paths, float *channel, float *tx) {
+    if (!s) return PBRT_E_INVALID;
+    pbrt_ctx *c = s->ctx;
+    NEED(c, p && channel);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t n = (size_t)p->n_angles * p->n_elements * p->time_samples;
+    void *d = c->buf("us_channel", n * 4);
+    if (!d) return PBRT_E_NOMEM;
+    int rc = us_impl(s, p, seed, ppr, path_offset, norm_paths, (float *)d, tx);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(channel, d, n * 4, hipMemcpyDeviceToHost));
+    return PBRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// leaf operators: stage host SoA through the workspace, one kernel, copy back
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct Stage {
+    pbrt_ctx *c;
+    char *base = nullptr;
+    size_t off = 0, cap = 0;
+    int rc = PBRT_OK;
+    Stage(pbrt_ctx *ctx, const char *name, size_t bytes) : c(ctx) {
+        base = (char *)c->buf(name, bytes + 1024);
+        cap = bytes + 1024;
+        if (!base) rc = PBRT_E_NOMEM;
+    }
+    template <typename T>
+    T *in(const T *h, size_t n) {
+        T *d = reinterpret_cast<T *>(base + off);
+        off += (n * sizeof(T) + 15) & ~size_t(15);
+        if (h && rc == PBRT_OK && hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, c->stream) != hipSuccess)
+            rc = c->fail(PBRT_E_DEVICE, "leaf upload failed");
+        return h ? d : nullptr;
+    }
+    template <typename T>
+    T *out(size_t n) {
+        T *d = reinterpret_cast<T *>(base + off);
+        off += (n * sizeof(T) + 15) & ~size_t(15);
+        return d;
+    }
+    template <typename T>
+    void back(T *h, const T *d, size_t n) {
+        if (rc == PBRT_OK && hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+            rc = c->fail(PBRT_E_DEVICE, "leaf download failed");
+    }
+    int finish() {
+        if (rc != PBRT_OK) return rc;
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return c->fail(PBRT_E_DEVICE, "leaf kernel: %s", hipGetErrorString(e));
+        return PBRT_OK;
+    }
+};
+
+extern "C" {
+
+#define LEAF_BEGIN(ctxp, total_bytes)          \
+    pbrt_ctx *c = (ctxp);                      \
+    if (!c) return PBRT_E_INVALID;             \
+    if (n == 0) return PBRT_OK;                \
+    HIPCHK(c, hipSetDevice(c->device));        \
+    Stage S(c, "leaf_io", (total_bytes));      \
+    if (S.rc) return S.rc;                     \
+    const dim3 grid(div_up(n, 256)), block(256); \
+    hipStream_t st = c->stream;
+
+int pbrt_ray_intersect(pbrt_scene *s, uint32_t n, const float *o, const float *d, const float *tmax, float *t,
+                       uint32_t *prim, float *u, float *v) {
+    if (!s) return PBRT_E_INVALID;
+    NEED(s->ctx, o && d && tmax && t && prim && u && v);
+    LEAF_BEGIN(s->ctx, (size_t)n * 4 * 12);
+    float *dO = S.in(o, 3 * (size_t)n), *dD = S.in(d, 3 * (size_t)n), *dT = S.in(tmax, n);
+    float *rt = S.out<float>(n), *ru = S.out<float>(n), *rv = S.out<float>(n);
+    uint32_t *rp = S.out<uint32_t>(n);
+    if (s->accel_kernel == ACCEL_K_BRUTE)
+        hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
+    else
+        hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
+    S.back(t, rt, n);
+    S.back(prim, rp, n);
+    S.back(u, ru, n);
+    S.back(v, rv, n);
+    return S.finish();
+}
+
+int pbrt_ray_test(pbrt_scene *s, uint32_t n, const float *o, const float *d, const float *tmax, uint8_t *hit) {
+    if (!s) return PBRT_E_INVALID;
+    NEED(s->ctx, o && d && tmax && hit);
+    LEAF_BEGIN(s->ctx, (size_t)n * 4 * 9);
+    float *dO = S.in(o, 3 * (size_t)n), *dD = S.in(d, 3 * (size_t)n), *dT = S.in(tmax, n);
+    uint8_t *rh = S.out<uint8_t>(n);
+    if (s->accel_kernel == ACCEL_K_BRUTE)
+        hipLaunchKernelGGL(k_ray_test<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
+    else
+        hipLaunchKernelGGL(k_ray_test<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
+    S.back(hit, rh, n);
+    return S.finish();
+}
+
+int pbrt_bsdf_sample(pbrt_ctx *ctx, const pbrt_material *m, uint32_t quirks, uint32_t n, const float *wi,
+                     const float *n_geo, const float *n_sh, const float *s1, const float *s2, float *wo, float *pdf,
+                     float *weight, uint32_t *sampled) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, m && wi && s1 && s2 && wo && pdf && weight && sampled);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 22);
+    float *dwi = S.in(wi, 3 * (size_t)n), *dng = S.in(n_geo, 3 * (size_t)n), *dns = S.in(n_sh, 3 * (size_t)n);
+    float *d1 = S.in(s1, n), *d2 = S.in(s2, 2 * (size_t)n);
+    float *rwo = S.out<float>(3 * (size_t)n), *rpdf = S.out<float>(n), *rw = S.out<float>(3 * (size_t)n);
+    uint32_t *rs = S.out<uint32_t>(n);
+    hipLaunchKernelGGL(k_bsdf_sample, grid, block, 0, st, *m, quirks, n, dwi, dng, dns, d1, d2, rwo, rpdf, rw, rs);
+    S.back(wo, rwo, 3 * (size_t)n);
+    S.back(pdf, rpdf, n);
+    S.back(weight, rw, 3 * (size_t)n);
+    S.back(sampled, rs, n);
+    return S.finish();
+}
+
+int pbrt_bsdf_eval_pdf(pbrt_ctx *ctx, const pbrt_material *m, uint32_t n, const float *wi, const float *wo, float *f,
+                       float *pdf) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, m && wi && wo && f && pdf);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 12);
+    float *dwi = S.in(wi, 3 * (size_t)n), *dwo = S.in(wo, 3 * (size_t)n);
+    float *rf = S.out<float>(3 * (size_t)n), *rp = S.out<float>(n);
+    hipLaunchKernelGGL(k_bsdf_eval_pdf, grid, block, 0, st, *m, n, dwi, dwo, rf, rp);
+    S.back(f, rf, 3 * (size_t)n);
+    S.back(pdf, rp, n);
+    return S.finish();
+}
+
+int pbrt_emitter_sample_direction(pbrt_scene *s, uint32_t n, const float *p, const float *u, float *d, float *dist,
+                                  float *pdf, float *weight, float *q, uint32_t *emitter) {
+    if (!s) return PBRT_E_INVALID;
+    NEED(s->ctx, p && u && d && dist && pdf && weight && q && emitter);
+    LEAF_BEGIN(s->ctx, (size_t)n * 4 * 22);
+    float *dp = S.in(p, 3 * (size_t)n), *du = S.in(u, 4 * (size_t)n);
+    float *rd = S.out<float>(3 * (size_t)n), *rdist = S.out<float>(n), *rpdf = S.out<float>(n);
+    float *rw = S.out<float>(3 * (size_t)n), *rq = S.out<float>(3 * (size_t)n);
+    uint32_t *re = S.out<uint32_t>(n);
+    hipLaunchKernelGGL(k_emitter_sample, grid, block, 0, st, s->ds, n, dp, du, rd, rdist, rpdf, rw, rq, re);
+    S.back(d, rd, 3 * (size_t)n);
+    S.back(dist, rdist, n);
+    S.back(pdf, rpdf, n);
+    S.back(weight, rw, 3 * (size_t)n);
+    S.back(q, rq, 3 * (size_t)n);
+    S.back(emitter, re, n);
+    return S.finish();
+}
+
+int pbrt_sensor_sample_ray(pbrt_ctx *ctx, const pbrt_camera *cam, uint32_t n, const float *pos, float *o, float *d,
+                           float *tmax) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, cam && pos && o && d && tmax);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 10);
+    float *dp = S.in(pos, 2 * (size_t)n);
+    float *ro = S.out<float>(3 * (size_t)n), *rd = S.out<float>(3 * (size_t)n), *rt = S.out<float>(n);
+    hipLaunchKernelGGL(k_sensor_sample_ray, grid, block, 0, st, *cam, n, dp, ro, rd, rt);
+    S.back(o, ro, 3 * (size_t)n);
+    S.back(d, rd, 3 * (size_t)n);
+    S.back(tmax, rt, n);
+    return S.finish();
+}
+
+int pbrt_us_sensor_sample_ray(pbrt_ctx *ctx, const pbrt_us_sensor *sn, int use_hemisphere_warp, uint32_t n,
+                              const float *time, const float *wavelength_sample, const float *position_sample,
+                              const float *aperture_sample, float *o, float *d, float *weight) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, sn && time && wavelength_sample && position_sample && aperture_sample && o && d && weight);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 14);
+    float *dt = S.in(time, n), *dw = S.in(wavelength_sample, n), *dp = S.in(position_sample, 2 * (size_t)n),
+          *da = S.in(aperture_sample, 2 * (size_t)n);
+    float *ro = S.out<float>(3 * (size_t)n), *rd = S.out<float>(3 * (size_t)n), *rw = S.out<float>(n);
+    hipLaunchKernelGGL(k_us_sensor_sample_ray, grid, block, 0, st, *sn, use_hemisphere_warp, n, dt, dw, dp, da, ro, rd, rw);
+    S.back(o, ro, 3 * (size_t)n);
+    S.back(d, rd, 3 * (size_t)n);
+    S.back(weight, rw, n);
+    return S.finish();
+}
+
+int pbrt_us_emitter_sample_ray(pbrt_ctx *ctx, const pbrt_us_emitter *e, uint32_t n, const float *time, const float *s1,
+                               const float *s2, const float *s3, float *o, float *d, float *ray_time, float *weight,
+                               float *pdf_pos) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, e && time && s1 && s2 && s3 && o && d && ray_time && weight && pdf_pos);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 16);
+    float *dt = S.in(time, n), *d1 = S.in(s1, n), *d2 = S.in(s2, 2 * (size_t)n), *d3 = S.in(s3, n);
+    float *ro = S.out<float>(3 * (size_t)n), *rd = S.out<float>(3 * (size_t)n), *rt = S.out<float>(n),
+          *rw = S.out<float>(n), *rp = S.out<float>(n);
+    hipLaunchKernelGGL(k_us_emitter_sample_ray, grid, block, 0, st, *e, n, dt, d1, d2, d3, ro, rd, rt, rw, rp);
+    S.back(o, ro, 3 * (size_t)n);
+    S.back(d, rd, 3 * (size_t)n);
+    S.back(ray_time, rt, n);
+    S.back(weight, rw, n);
+    S.back(pdf_pos, rp, n);
+    return S.finish();
+}
+
+int pbrt_us_put_data(pbrt_ctx *ctx, const pbrt_us_receiver *r, uint32_t n, const float *ox, const float *time,
+                     const float *d, const float *amplitude, float *channel_buffer) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, r && ox && time && d && amplitude && channel_buffer);
+    const size_t nb = (size_t)r->number_of_elements * r->time_samples;
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 7 + nb * 4);
+    float *dx = S.in(ox, n), *dt = S.in(time, n), *dd = S.in(d, 3 * (size_t)n), *da = S.in(amplitude, n);
+    float *db = S.in(channel_buffer, nb);
+    hipLaunchKernelGGL(k_us_put_data, grid, block, 0, st, *r, n, dx, dt, dd, da, db);
+    S.back(channel_buffer, db, nb);
+    return S.finish();
+}
+
+}  // extern "C"

@@ -20,7 +20,7 @@ from ._capi import (USQ_CLAMP_TIME, USQ_DIAG_SAMPLE, USQ_DOUBLE_LOCAL, USQ_MIXED
                     USQ_NO_TOF_ACCUM, USQ_REF_REFLECT, USQ_REFERENCE, USQ_UNIT_GGX_PDF, Context, HipLibraryMissing,
                     default_context, load_library)
 from .plugins import (AreaEmitter, BSDF, BSDFContext, BSDFFlags, BSDFSample3f, ConductorBSDF, CustomEmitter,
-                      CustomSensor, DielectricBSDF, DiffuseBSDF, DirectIntegrator, DrArray, Emitter, EmitterFlags,
+                      DielectricBSDF, DiffuseBSDF, DirectIntegrator, DrArray, Emitter, EmitterFlags,
                       PathIntegrator, PerspectiveSensor, PointEmitter, SamplingIntegrator, Sensor,
                       SurfaceInteraction3f, UltraBSDF, UltraIntegrator, UltraSensor)
 from .scene import (Film, Object, ParamFlags, ReconstructionFilter, Sampler, Scene, SceneParameters, Shape, load_dict,
@@ -28,6 +28,8 @@ from .scene import (Film, Object, ParamFlags, ReconstructionFilter, Sampler, Sce
                     register_sampler, register_sensor, register_shape, traverse)
 from .transforms import Properties, ScalarTransform4f, Transform4f
 
+# NB: the receive-side accumulator class `CustomSensor` is reached as pbrt_amd.CustomSensor.CustomSensor (module of
+# the same name, like the reference's CustomSensor.py) or pbrt_amd.plugins.CustomSensor.
 __version__ = "0.1.0"
 
 _VARIANTS = ("hip_gfx950", "scalar_rgb", "scalar_mono", "llvm_ad_rgb", "llvm_ad_mono", "cuda_ad_rgb", "cuda_ad_mono")

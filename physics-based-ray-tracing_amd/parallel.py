@@ -1,0 +1,131 @@
+"""Multi-GPU sharding of the hot path: one process per GPU (torch.distributed; backend "nccl" is RCCL
+over xGMI on ROCm, "gloo" on CPU for tests).
+
+Radiance mode  -- the film is cut into interleaved bands of `band_rows` rows; rank r owns bands
+    r, r + G, r + 2G, ...  Each rank renders its bands with the SAME global RNG keys (pixel, sample) as
+    a single-GPU render; the library renders the filter halo rows around a band redundantly, so the
+    stitched image is bit-identical to the single-GPU image.  No collective on the data path; ONE
+    gather of finished bands to rank 0 at the end.
+Ultrasound mode -- the P paths of every (angle, element) ray are split into contiguous ranges; every
+    rank accumulates its own channel buffer (already divided by the total P) and ONE reduce(sum) adds
+    them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def band_layout(height: int, world_size: int, band_rows: int = 64):
+    """-> list over ranks of [(y0, rows), ...]; bands dealt round-robin."""
+    bands = [(y, min(band_rows, height - y)) for y in range(0, height, band_rows)]
+    return [[b for i, b in enumerate(bands) if i % world_size == r] for r in range(world_size)]
+
+
+def rows_of(layout_rank):
+    return sum(r for _, r in layout_rank)
+
+
+def path_ranges(paths_per_ray: int, world_size: int):
+    """-> [(offset, count)] contiguous split of the per-ray path index"""
+    base, rem = divmod(paths_per_ray, world_size)
+    out, off = [], 0
+    for r in range(world_size):
+        c = base + (1 if r < rem else 0)
+        out.append((off, c))
+        off += c
+    return out
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=None, device=None, sample_offset=0):
+    """Render this rank's bands into one [rows_max, W, 3] float32 torch tensor (padded to the largest
+    rank).  render_band(crop, out_rows_tensor) fills a [rows, W, 3] view; the default calls the HIP
+    library and writes straight into the tensor's device memory (no PCIe traffic)."""
+    import torch
+
+    sens = scene.sensors()[0]
+    W, H = sens.film().size()
+    layout = band_layout(H, world_size, band_rows)
+    rows_max = max(rows_of(l) for l in layout)
+    dev = device if device is not None else torch.device("cpu")
+    tile = torch.zeros((rows_max, W, 3), dtype=torch.float32, device=dev)
+    integ = scene.integrator()
+    off = 0
+    for (y0, rows) in layout[rank]:
+        view = tile[off:off + rows]
+        crop = (0, y0, W, rows)
+        if render_band is not None:
+            render_band(crop, view)
+        else:
+            if dev.type != "cuda":
+                raise RuntimeError("the HIP render path needs a device tensor (torch 'cuda' == HIP on ROCm)")
+            integ.render(scene, sensor=sens, seed=seed, spp=spp, crop=crop, sample_offset=sample_offset,
+                         out_dev=view.data_ptr())
+        off += rows
+    return tile, layout
+
+
+def gather_film(tile, layout, width, height, rank, world_size, group=None):
+    """One gather of every rank's tile to rank 0, then de-interleave.  -> [H, W, 3] tensor on rank 0, None elsewhere."""
+    import torch
+
+    dist = _dist()
+    if world_size == 1:
+        parts = [tile]
+    else:
+        parts = [torch.empty_like(tile) for _ in range(world_size)] if rank == 0 else None
+        dist.gather(tile, gather_list=parts, dst=0, group=group)
+        if rank != 0:
+            return None
+    film = torch.empty((height, width, 3), dtype=tile.dtype, device=tile.device)
+    for r in range(world_size):
+        off = 0
+        for (y0, rows) in layout[r]:
+            film[y0:y0 + rows] = parts[r][off:off + rows]
+            off += rows
+    return film
+
+
+def distributed_render(scene, spp, seed=0, band_rows=64, render_band=None, device=None, group=None):
+    """Whole job: render this rank's bands, gather on rank 0.  Works for world_size 1 without an
+    initialised process group."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    tile, layout = render_tiles(scene, spp, seed, rank, world, band_rows, render_band, device)
+    W, H = scene.sensors()[0].film().size()
+    return gather_film(tile, layout, W, H, rank, world, group)
+
+
+def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None):
+    """Ultrasound: every rank traces its path range into its own (already normalised) channel buffer;
+    one reduce(sum) to rank 0.  acquire(offset, count, norm, out_tensor) fills the tensor; the default
+    calls the HIP library on the tensor's device memory.  -> [n_angles, n_elements, T] tensor on rank 0."""
+    import torch
+
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    ui = scene.integrator()
+    off, cnt = path_ranges(paths_per_ray, world)[rank]
+    dev = device if device is not None else torch.device("cpu")
+    buf = torch.zeros((ui.n_angles, ui.n_elements, ui.time_samples), dtype=torch.float32, device=dev)
+    if cnt > 0:
+        if acquire is not None:
+            acquire(off, cnt, paths_per_ray, buf)
+        else:
+            if dev.type != "cuda":
+                raise RuntimeError("the HIP acquisition path needs a device tensor")
+            ui._acquire(scene, ui.quirks, paths_per_ray=cnt, path_offset=off, norm_paths=paths_per_ray, seed=seed,
+                        out_dev=buf.data_ptr())
+    if world > 1:
+        dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+    return buf if rank == 0 else None

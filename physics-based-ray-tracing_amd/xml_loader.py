@@ -89,7 +89,7 @@ def _plugin(el, env, base_dir, counters) -> dict:
         if tag == "default":
             continue
         if tag in PLUGIN_TAGS:
-            key = name or ch.attrib.get("id") or (_NESTED_KEY.get(tag) if el.tag != "scene" else None)
+            key = name or ch.attrib.get("id") or _NESTED_KEY.get(tag)
             if not key or key in d:
                 counters[tag] = counters.get(tag, 0) + 1
                 key = f"{tag}_{counters[tag]}"

@@ -1,0 +1,96 @@
+"""The drop-in boundary: libpbrt_hip.so loads and exports every symbol include/pbrt_hip.h declares; the
+product never reaches into oracle/; without a GPU the hot path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, scene_path
+
+PKG = os.path.join(ROOT, "physics-based-ray-tracing_amd")
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pbrt_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbrt_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_are_all_bound_and_exported(capi):
+    declared = _declared_symbols()
+    assert len(declared) >= 23
+    assert sorted(capi.SIGNATURES.keys()) == declared
+    lib = capi.load_library()          # raises AttributeError on a missing export
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pbrt_abi_version() == capi.PBRT_ABI_VERSION
+
+
+def test_struct_layouts_match_the_header(capi):
+    """sizeof() of every ctypes mirror == sizeof() of the C struct (compiled with gcc)."""
+    names = {"pbrt_prim": 64, "pbrt_material": C.sizeof(capi.Material), "pbrt_emitter": 48,
+             "pbrt_scene_desc": C.sizeof(capi.SceneDesc), "pbrt_camera": C.sizeof(capi.Camera),
+             "pbrt_film_desc": C.sizeof(capi.FilmDesc), "pbrt_us_params": C.sizeof(capi.UsParams),
+             "pbrt_us_sensor": C.sizeof(capi.UsSensor), "pbrt_us_emitter": C.sizeof(capi.UsEmitter),
+             "pbrt_us_receiver": C.sizeof(capi.UsReceiver), "pbrt_stats": C.sizeof(capi.Stats)}
+    prog = '#include <stdio.h>\n#include "pbrt_hip.h"\nint main(){' + "".join(
+        f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    exe = os.path.join(ROOT, "oracle", "_build", "abi_sizes")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=prog.encode(), check=True)
+    out = dict(line.split() for line in subprocess.check_output([exe]).decode().splitlines())
+    for n, size in names.items():
+        assert int(out[n]) == size, n
+    assert capi.PRIM_DTYPE.itemsize == 64 and capi.EMITTER_DTYPE.itemsize == 48 and capi.MATERIAL_DTYPE.itemsize == 32
+
+
+def test_product_code_never_touches_the_oracle():
+    pat = re.compile(r"oracle", re.I)
+    for dirpath, _, files in os.walk(PKG):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                hits = [ln for ln in text.splitlines() if pat.search(ln) and "import" in ln or "liboracle" in ln or "#include \"../../oracle" in ln]
+                assert not hits, (fn, hits)
+    text = open(os.path.join(PKG, "csrc", "Makefile")).read()
+    assert "oracle" not in text
+
+
+def test_missing_library_is_loud(capi, tmp_path):
+    with pytest.raises(capi.HipLibraryMissing):
+        capi.load_library(str(tmp_path / "nope.so"))
+
+
+def _have_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(_have_gpu(), reason="checks the no-GPU behaviour")
+def test_no_gpu_means_error_not_fallback(mi, capi):
+    lib = capi.load_library()
+    h = C.c_void_p()
+    rc = lib.pbrt_ctx_create(0, C.byref(h))
+    assert rc == -2 and b"no HIP device" in lib.pbrt_last_error(None)
+    sc = mi.load_file(scene_path("cbox.xml"), res=8, spp=1)
+    with pytest.raises(RuntimeError, match="pbrt_ctx_create"):
+        mi.render(sc)
+    us = mi.load_file(scene_path("us_plate.xml"))
+    with pytest.raises(RuntimeError):
+        us.integrator().simulate_acquisition_parallel(us)
+    with pytest.raises(RuntimeError):
+        mi.UltraBSDF(mi.Properties("ultrasound_bsdf")).sample(None, mi.SurfaceInteraction3f([[0, 0, 1]]), 0.5, 0.5)
+
+
+def test_invalid_arguments_return_error_codes(capi):
+    lib = capi.load_library()
+    assert lib.pbrt_ctx_create(0, None) == -1
+    assert lib.pbrt_get_stats(None, None) == -1
+    assert lib.pbrt_us_tx_delays(None, None) == -1
+    assert lib.pbrt_scene_create(None, None, None) == -1
+    assert lib.pbrt_render_radiance(None, None, None, None) == -1
+    assert lib.pbrt_ray_intersect(None, 0, None, None, None, None, None, None, None) == -1
+    assert lib.pbrt_ctx_destroy(None) == 0 and lib.pbrt_scene_destroy(None) == 0

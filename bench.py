@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-spp", type=int, default=32)
+    ap.add_argument("--cpu-spp", type=int, default=0, help="0: pick the largest power of two <= 256 that takes about 15 s")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(visible cores, 64)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,10 +141,17 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob
-            cores = len(os.sched_getaffinity(0))
+            cores = args.cpu_threads or min(len(os.sched_getaffinity(0)), 64)
             integ, sens = scene.integrator(), scene.sensors()[0]
-            fd = integ._film_desc(scene, sens, seed, args.cpu_spp)
             osc = ob.OracleScene.from_scene(scene)
+            if not args.cpu_spp:  # calibrate on 2 spp, then take ~15 s worth of samples (bounded by the full 256)
+                tc = time.perf_counter()
+                osc.render(sens.camera(), integ._film_desc(scene, sens, seed, 2), n_threads=cores)
+                per_spp = (time.perf_counter() - tc) / 2
+                args.cpu_spp = 1
+                while args.cpu_spp < SPP_PER_GPU and per_spp * args.cpu_spp * 2 <= 15.0:
+                    args.cpu_spp *= 2
+            fd = integ._film_desc(scene, sens, seed, args.cpu_spp)
             tc = time.perf_counter()
             ref = osc.render(sens.camera(), fd, n_threads=cores)
             tcpu = time.perf_counter() - tc

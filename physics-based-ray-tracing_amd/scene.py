@@ -460,8 +460,8 @@ class Scene(Object):
         sph = typ == _capi.PRIM_SPHERE
         if np.any(sph):
             ps = o + t[:, None] * d
-            ns = ps - g[:, 0:3]
-            ns /= np.maximum(np.linalg.norm(ns, axis=1, keepdims=True), 1e-30)
+            ns = np.where(sph[:, None], ps - g[:, 0:3], 1.0)
+            ns = ns / np.maximum(np.linalg.norm(ns, axis=1, keepdims=True), 1e-30)
             p = np.where(sph[:, None], g[:, 0:3] + ns * g[:, 3:4], p)
             nrm = np.where(sph[:, None], ns, nrm)
         p[~valid] = 0

@@ -97,7 +97,7 @@ def test_crop_sample_offset_raw_and_pass_size(mi, ob):
     assert np.allclose(r0 + r1, rr, rtol=1e-6, atol=1e-7)
     ref_raw, _ = oracle_render(ob, sc, 4, 4, sample_offset=8, raw=True)
     assert np.array_equal(r1, ref_raw)
-    assert np.array_equal(rr[..., :3] / rr[..., 3:4], full)
+    assert np.array_equal(rr[..., :3] * (np.float32(1.0) / rr[..., 3:4]), full)      # resolve multiplies by 1/w
 
 
 def test_non_square_film_and_camera(mi, ob):

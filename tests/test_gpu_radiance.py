@@ -192,7 +192,8 @@ def test_full_size_matches_oracle_on_a_band(mi, ob, cbox_full):
 
 def test_full_size_energy_sanity(cbox_full):
     _, img, _ = cbox_full
-    lum = img[8:24, 224:288]                       # the luminaire seen directly: radiance 1 (+ little reflected light)
+    # the luminaire (y = 0.99, |x|,|z| <= 0.25) projects to rows 67..89, columns 211..301: radiance 1 seen directly
+    lum = img[70:86, 220:292]
     assert 0.99 <= np.median(lum) <= 1.2
     assert img[:, :170].mean(axis=(0, 1)).argmax() == 1   # left third is dominated by the green wall
     assert img[:, 342:].mean(axis=(0, 1)).argmax() == 0   # right third by the red wall

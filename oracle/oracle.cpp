@@ -108,6 +108,48 @@ inline bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float
     return false;  // CONE: not built yet
 }
 
+// Brute-force scenes (<= 32 primitives, walked in index order by every ray): candidate hit as the
+// ratio t = num / den (den > 0), barycentrics scaled by den.  No division per candidate: the range
+// test is ts <= tmax * det, candidates are ranked by cross-multiplication (closest_hit below) and
+// the one division happens after the loop.  Spheres report (t, 1).  DESIGN.md "Intersection".
+inline bool prim_candidate(const pbrt_prim &P, V3 o, V3 d, float tmax, float *num, float *den, float *us_, float *vs_) {
+    if (P.type == PBRT_PRIM_SPHERE) {
+        float t, u, v;
+        if (!prim_hit(P, o, d, tmax, &t, &u, &v)) return false;
+        *num = t;
+        *den = 1.0f;
+        *us_ = 0.0f;
+        *vs_ = 0.0f;
+        return true;
+    }
+    if (P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM) {
+        V3 v0 = g3(P, 0), e1 = g3(P, 3), e2 = g3(P, 6);
+        V3 pvec = cross(d, e2);
+        float det = dot(e1, pvec);
+        V3 tvec = o - v0;
+        V3 qvec = cross(tvec, e1);
+        float us = dot(tvec, pvec), vs = dot(d, qvec), ts = dot(e2, qvec);
+        if (det < 0.0f) {
+            det = -det;
+            us = -us;
+            vs = -vs;
+            ts = -ts;
+        }
+        bool ok = det > 0.0f && us >= 0.0f && vs >= 0.0f && ts >= 0.0f && ts <= tmax * det;
+        if (P.type == PBRT_PRIM_TRIANGLE)
+            ok = ok && (us + vs <= det);
+        else
+            ok = ok && (us <= det) && (vs <= det);
+        if (!ok) return false;
+        *num = ts;
+        *den = det;
+        *us_ = us;
+        *vs_ = vs;
+        return true;
+    }
+    return false;
+}
+
 inline bool box_hit(const BvhNode &n, V3 o, V3 inv_d, float tbest) {
     float tx0 = (n.lo[0] - o.x) * inv_d.x, tx1 = (n.hi[0] - o.x) * inv_d.x;
     float ty0 = (n.lo[1] - o.y) * inv_d.y, ty1 = (n.hi[1] - o.y) * inv_d.y;
@@ -130,12 +172,23 @@ bool closest_hit(const Scene &sc, V3 o, V3 d, float tmax, Hit *h) {
     h->u = h->v = 0.0f;
     bool found = false;
     if (!sc.use_bvh) {
+        float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
         for (uint32_t i = 0; i < sc.prims.size(); ++i) {
-            float t, u, v;
-            if (prim_hit(sc.prims[i], o, d, h->t, &t, &u, &v) && (!found || t < h->t)) {
-                *h = {t, u, v, i};
+            float num, den, us, vs;
+            if (prim_candidate(sc.prims[i], o, d, tmax, &num, &den, &us, &vs) && (!found || num * bd < bn * den)) {
+                bn = num;
+                bd = den;
+                bu = us;
+                bv = vs;
+                h->prim = i;
                 found = true;
             }
+        }
+        if (found) {
+            float inv = 1.0f / bd;
+            h->t = bn * inv;
+            h->u = bu * inv;
+            h->v = bv * inv;
         }
         return found;
     }
@@ -166,8 +219,8 @@ bool closest_hit(const Scene &sc, V3 o, V3 d, float tmax, Hit *h) {
 bool any_hit(const Scene &sc, V3 o, V3 d, float tmax) {
     if (!sc.use_bvh) {
         for (uint32_t i = 0; i < sc.prims.size(); ++i) {
-            float t, u, v;
-            if (prim_hit(sc.prims[i], o, d, tmax, &t, &u, &v)) return true;
+            float num, den, us, vs;
+            if (prim_candidate(sc.prims[i], o, d, tmax, &num, &den, &us, &vs)) return true;
         }
         return false;
     }

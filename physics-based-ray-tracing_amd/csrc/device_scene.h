@@ -92,24 +92,69 @@ DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u
 
 // ---- brute force: every lane walks the same primitive sequence, so the records come through the
 // scalar cache (s_load) and cost no vector memory traffic -----------------------------------------
+//
+// Candidates are ratios t = num / den (den > 0): the range test is ts <= tmax * det, candidates are
+// ranked by cross-multiplication and the one division happens after the loop, so the loop body of a
+// triangle / parallelogram is straight-line code (selects, no divergent branch, no division).
 template <bool ANY>
 DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     bool found = false;
-    float best = tmax;
+    float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
+    uint32_t bp = 0xffffffffu;
     for (uint32_t i = 0; i < sc.n_prims; ++i) {
-        float t, u, v;
-        if (prim_hit(sc.prims[i], o, d, best, &t, &u, &v)) {
-            if (ANY) return true;
-            if (!found || t < best) {
-                best = t;
-                h->t = t;
-                h->u = u;
-                h->v = v;
-                h->prim = i;
-                h->slot = i;
-                found = true;
-            }
+        const pbrt_prim &P = sc.prims[i];
+        const uint32_t type = P.type;  // wave-uniform
+        bool ok;
+        float num, den, us, vs;
+        if (type == PBRT_PRIM_SPHERE) {
+            float t, u, v;
+            ok = prim_hit(P, o, d, tmax, &t, &u, &v);
+            num = t;
+            den = 1.0f;
+            us = 0.0f;
+            vs = 0.0f;
+        } else {
+            V3 v0 = g3(P, 0), e1 = g3(P, 3), e2 = g3(P, 6);
+            V3 pvec = cross(d, e2);
+            float det = dot(e1, pvec);
+            V3 tvec = o - v0;
+            V3 qvec = cross(tvec, e1);
+            us = dot(tvec, pvec);
+            vs = dot(d, qvec);
+            float ts = dot(e2, qvec);
+            const bool neg = det < 0.0f;
+            det = neg ? -det : det;
+            us = neg ? -us : us;
+            vs = neg ? -vs : vs;
+            ts = neg ? -ts : ts;
+            ok = (det > 0.0f) & (us >= 0.0f) & (vs >= 0.0f) & (ts >= 0.0f) & (ts <= tmax * det);
+            if (type == PBRT_PRIM_TRIANGLE)
+                ok = ok & (us + vs <= det);
+            else
+                ok = ok & (us <= det) & (vs <= det);
+            num = ts;
+            den = det;
         }
+        if (ANY) {
+            found = found | ok;
+            if (__builtin_amdgcn_ballot_w64(!found) == 0) break;  // every active lane is occluded
+        } else {
+            const bool better = ok & (!found | (num * bd < bn * den));
+            bn = better ? num : bn;
+            bd = better ? den : bd;
+            bu = better ? us : bu;
+            bv = better ? vs : bv;
+            bp = better ? i : bp;
+            found = found | better;
+        }
+    }
+    if (!ANY && found) {
+        float inv = 1.0f / bd;
+        h->t = bn * inv;
+        h->u = bu * inv;
+        h->v = bv * inv;
+        h->prim = bp;
+        h->slot = bp;
     }
     return found;
 }

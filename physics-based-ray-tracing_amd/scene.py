@@ -166,15 +166,39 @@ class MeshShape(Shape):
         v, t = load_mesh(self.filename)
         self.vertices = self.to_world.transform_affine(v)
         self.faces = t
-        if props.get("face_normals", False) is False and False:
-            pass  # vertex normals are not used: face normals only
+        # vertex normals are not used: face normals only
+        self.merge_quads = bool(props.get("merge_quads", True))
 
     def primitives(self):
+        """Triangles; a fan pair (a,b,c),(a,c,d) whose f32 corners form an exact parallelogram
+        (a + c == b + d component-wise) becomes ONE analytic PARALLELOGRAM primitive -- the same
+        surface, one intersection test instead of two ("analytic quads", BASELINE config 2)."""
         v = self.vertices
         t = self.faces
         if self.flip_normals:
             t = t[:, [0, 2, 1]]
-        return _tri_records(v[t[:, 0]], v[t[:, 1]], v[t[:, 2]], _capi.PRIM_TRIANGLE)
+        vf = v.astype(np.float32)
+        merged = np.zeros(len(t), bool)   # second triangle of a merged pair
+        quad = np.zeros(len(t), bool)     # first triangle of a merged pair
+        if self.merge_quads and len(t) >= 2:
+            a, b, c = t[:-1, 0], t[:-1, 1], t[:-1, 2]
+            a2, c2, d2 = t[1:, 0], t[1:, 1], t[1:, 2]
+            cand = (a == a2) & (c == c2) & np.all(vf[a] + vf[c] == vf[b] + vf[d2], axis=1)
+            k = 0
+            while k < len(cand):      # greedy, non-overlapping pairs
+                if cand[k]:
+                    quad[k] = True
+                    merged[k + 1] = True
+                    k += 2
+                else:
+                    k += 1
+        rec = _tri_records(v[t[:, 0]], v[t[:, 1]], v[t[:, 2]], _capi.PRIM_TRIANGLE)
+        if quad.any():
+            qi = np.nonzero(quad)[0]
+            q = _tri_records(v[t[qi, 0]], v[t[qi, 1]], v[t[qi + 1, 2]], _capi.PRIM_PARALLELOGRAM)
+            rec[qi] = q
+            rec = rec[~merged]
+        return rec
 
 
 class SphereShape(Shape):

@@ -23,28 +23,33 @@ def test_cbox_geometry_k7(mi, capi, known):
     sc = mi.load_file(scene_path("cbox.xml"), res=64, spp=4)
     f = sc.flatten()
     P = f["prims"]
-    assert len(P) == 14 and list(P["type"]) == [0] * 12 + [1, 1]
+    assert len(P) == 8 and list(P["type"]) == [2] * 6 + [1, 1]      # six analytic quads (merged fan pairs) + two spheres
+    sc_t = mi.load_file(scene_path("cbox.xml"), res=64, spp=4)
+    for s_ in sc_t.shapes():
+        if hasattr(s_, "merge_quads"):
+            s_.merge_quads = False
+    assert list(sc_t.flatten()["prims"]["type"]) == [0] * 12 + [1, 1]   # Mitsuba's own triangulation, on request
     shapes = {s.id(): i for i, s in enumerate(sc.shapes())}
     for name, key, axis in (("floor", "floor", 1), ("ceiling", "ceiling", 1), ("back", "back", 2), ("left", "green", 0),
                             ("right", "red", 0)):
         tri = P[P["shape"] == shapes[name]]
-        assert len(tri) == 2
+        assert len(tri) == 1
         coord = k[key][{0: "x", 1: "y", 2: "z"}[axis]]
         for t in tri:
             v0, e1, e2 = t["g"][0:3], t["g"][3:6], t["g"][6:9]
-            for v in (v0, v0 + e1, v0 + e2):
+            for v in (v0, v0 + e1, v0 + e2, v0 + e1 + e2):
                 assert v[axis] == pytest.approx(coord) and np.all(np.abs(v) <= 1 + 1e-6)
             assert np.allclose(t["g"][9:12], k[key]["n"], atol=1e-6)
     lum = P[P["shape"] == shapes["luminaire"]]
-    assert np.allclose(lum["g"][:, 9:12], [k["luminaire"]["n"]] * 2, atol=1e-6)
+    assert np.allclose(lum["g"][:, 9:12], [k["luminaire"]["n"]], atol=1e-6)
     assert np.allclose(lum["g"][:, 1], k["luminaire"]["y"], atol=1e-6)
-    assert list(lum["emitter"]) == [0, 0] and f["emitters"]["area"][0] == pytest.approx(k["luminaire"]["area"])
+    assert list(lum["emitter"]) == [0] and f["emitters"]["area"][0] == pytest.approx(k["luminaire"]["area"])
     assert np.allclose(f["emitters"]["radiance"][0], [1, 1, 1])
-    assert np.allclose(P["g"][12, :4], k["mirror_sphere"]["c"] + [k["mirror_sphere"]["r"]], atol=1e-6)
-    assert np.allclose(P["g"][13, :4], k["glass_sphere"]["c"] + [k["glass_sphere"]["r"]], atol=1e-6)
+    assert np.allclose(P["g"][6, :4], k["mirror_sphere"]["c"] + [k["mirror_sphere"]["r"]], atol=1e-6)
+    assert np.allclose(P["g"][7, :4], k["glass_sphere"]["c"] + [k["glass_sphere"]["r"]], atol=1e-6)
     mats = f["materials"]
-    assert mats["type"][P["material"][12]] == capi.MAT_CONDUCTOR and mats["type"][P["material"][13]] == capi.MAT_DIELECTRIC
-    assert mats["p"][P["material"][13], 0] == pytest.approx(1.5046 / 1.000277, rel=1e-6)
+    assert mats["type"][P["material"][6]] == capi.MAT_CONDUCTOR and mats["type"][P["material"][7]] == capi.MAT_DIELECTRIC
+    assert mats["p"][P["material"][7], 0] == pytest.approx(1.5046 / 1.000277, rel=1e-6)
     sens = sc.sensors()[0]
     assert sens.x_fov == pytest.approx(k["x_fov_deg"]) and np.allclose(sens.transform.translation(), k["camera_origin"])
     cam = sens.camera()

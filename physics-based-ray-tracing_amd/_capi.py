@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpbrt_hip.so")
+LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbrt_hip.so")  # override: A/B builds
 
 PBRT_ABI_VERSION = 1
 

@@ -180,3 +180,57 @@ inline void build_bvh(const pbrt_prim *prims, uint32_t n, HostBvh *out) {
     out->max_depth = 0;
     b.build(0, 0, n, 0);
 }
+
+// ---- inner-node form for the stackless device traversal (DevNode in device_scene.h) ---------------
+struct HostInner {
+    float lo0[3];
+    uint32_t c0;
+    float hi0[3];
+    uint32_t c1;
+    float lo1[3];
+    uint32_t parent;
+    float hi1[3];
+    uint32_t pad;
+};
+
+namespace bvh_detail {
+inline uint32_t emit_inner(const HostBvh &b, uint32_t old_idx, uint32_t parent, std::vector<HostInner> *out) {
+    const HostNode &n = b.nodes[old_idx];
+    if (!(n.b & 0x80000000u)) return 0x80000000u | ((n.b & 15u) << 27) | (n.a & 0x07ffffffu);  // leaf reference
+    const uint32_t idx = (uint32_t)out->size();
+    out->push_back(HostInner{});
+    const HostNode &l = b.nodes[n.a], &r = b.nodes[n.a + 1];
+    HostInner in{};
+    for (int k = 0; k < 3; ++k) {
+        in.lo0[k] = l.lo[k];
+        in.hi0[k] = l.hi[k];
+        in.lo1[k] = r.lo[k];
+        in.hi1[k] = r.hi[k];
+    }
+    in.parent = parent;
+    in.c0 = emit_inner(b, n.a, idx, out);
+    in.c1 = emit_inner(b, n.a + 1, idx, out);
+    (*out)[idx] = in;
+    return idx;
+}
+}  // namespace bvh_detail
+
+inline void to_inner_nodes(const HostBvh &b, std::vector<HostInner> *out) {
+    out->clear();
+    const HostNode &root = b.nodes[0];
+    if (!(root.b & 0x80000000u)) {  // the whole scene is one leaf: wrap it
+        HostInner in{};
+        for (int k = 0; k < 3; ++k) {
+            in.lo0[k] = root.lo[k];
+            in.hi0[k] = root.hi[k];
+            in.lo1[k] = INFINITY;
+            in.hi1[k] = -INFINITY;
+        }
+        in.c0 = 0x80000000u | ((root.b & 15u) << 27) | (root.a & 0x07ffffffu);
+        in.c1 = 0x80000000u;  // empty leaf
+        in.parent = 0;
+        out->push_back(in);
+        return;
+    }
+    bvh_detail::emit_inner(b, 0, 0, out);
+}

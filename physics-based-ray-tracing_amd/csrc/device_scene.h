@@ -5,14 +5,22 @@
 #include "../../include/pbrt_hip.h"
 #include "device_math.h"
 
-// BVH2 node, 32 bytes.  leaf: a = first primitive (leaf order), b = count (1..8);
-// internal: a = index of the left child (right child = a + 1), b = 0x80000000 | split axis.
+// BVH2 inner node, 64 bytes: the boxes of BOTH children plus their references, so one node read
+// decides both descents.  Child reference c: bit 31 set = leaf, bits 27..30 = primitive count (0..15),
+// bits 0..26 = first primitive (leaf order); bit 31 clear = index of an inner node.
+// `parent` = index of the parent inner node (root: 0).  Traversal keeps no stack: a 64-bit trail of
+// "far sibling still pending" bits plus the parent links (bit-trail traversal, Afra & Szirmay-Kalos).
 struct DevNode {
-    float lo[3];
-    uint32_t a;
-    float hi[3];
-    uint32_t b;
+    float lo0[3];
+    uint32_t c0;
+    float hi0[3];
+    uint32_t c1;
+    float lo1[3];
+    uint32_t parent;
+    float hi1[3];
+    uint32_t pad;
 };
+#define BVH_LEAF 0x80000000u
 
 struct DevScene {
     const pbrt_prim *prims;  // BRUTE: caller order.  BVH: leaf order
@@ -101,8 +109,12 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     bool found = false;
     float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bp = 0xffffffffu;
+    // software pipeline over the (wave-uniform) primitive records: the 64-byte scalar load of primitive
+    // i + 1 is in flight while primitive i is tested
+    pbrt_prim nxt = sc.prims[0];
     for (uint32_t i = 0; i < sc.n_prims; ++i) {
-        const pbrt_prim &P = sc.prims[i];
+        const pbrt_prim P = nxt;
+        nxt = sc.prims[min(i + 1, sc.n_prims - 1)];
         const uint32_t type = P.type;  // wave-uniform
         bool ok;
         float num, den, us, vs;
@@ -159,36 +171,43 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     return found;
 }
 
-// ---- BVH2 traversal; NodeP / PrimP are global or LDS pointers ----------------------------------
+// ---- BVH2 traversal without a stack; NodeP / PrimP / IdP are global or LDS pointers -------------
+// Box tests are conservative (boxes are padded at build time, reciprocal directions are approximate);
+// only prim_hit decides, and ties in t go to the lowest primitive id, so the result does not depend on
+// the tree or on the visiting order.
+DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 inv, float best, float *tn_) {
+    float tx0 = (lox - o.x) * inv.x, tx1 = (hix - o.x) * inv.x;
+    float ty0 = (loy - o.y) * inv.y, ty1 = (hiy - o.y) * inv.y;
+    float tz0 = (loz - o.z) * inv.z, tz1 = (hiz - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best));
+    *tn_ = tn;
+    return tn <= tf;
+}
+
 template <bool ANY, typename NodeP, typename PrimP, typename IdP>
 DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
     const V3 inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
-    uint32_t stack[32];
-    int sp = 0;
     uint32_t node = 0;
+    unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
     bool found = false;
     float best = tmax;
     for (;;) {
-        const float lox = nodes[node].lo[0], loy = nodes[node].lo[1], loz = nodes[node].lo[2];
-        const float hix = nodes[node].hi[0], hiy = nodes[node].hi[1], hiz = nodes[node].hi[2];
-        const uint32_t na = nodes[node].a, nb = nodes[node].b;
-        float tx0 = (lox - o.x) * inv.x, tx1 = (hix - o.x) * inv.x;
-        float ty0 = (loy - o.y) * inv.y, ty1 = (hiy - o.y) * inv.y;
-        float tz0 = (loz - o.z) * inv.z, tz1 = (hiz - o.z) * inv.z;
-        float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-        float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best));
-        bool descend = false;
-        if (tn <= tf) {
-            if (nb & 0x80000000u) {
-                const uint32_t axis = nb & 3u;
-                const float dax = axis == 0 ? d.x : (axis == 1 ? d.y : d.z);
-                const uint32_t near_c = dax < 0.0f ? na + 1 : na, far_c = dax < 0.0f ? na : na + 1;
-                stack[sp++] = far_c;
-                node = near_c;
-                descend = true;
-            } else {
-                for (uint32_t k = 0; k < nb; ++k) {
-                    const uint32_t slot = na + k;
+        const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
+        float t0, t1;
+        bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0], nodes[node].hi0[1],
+                           nodes[node].hi0[2], o, inv, best, &t0);
+        bool h1 = box_test(nodes[node].lo1[0], nodes[node].lo1[1], nodes[node].lo1[2], nodes[node].hi1[0], nodes[node].hi1[1],
+                           nodes[node].hi1[2], o, inv, best, &t1);
+        // leaves are tested on the spot
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t c = side ? c1 : c0;
+            const bool hit = side ? h1 : h0;
+            if (hit && (c & BVH_LEAF)) {
+                const uint32_t first = c & 0x07ffffffu, count = (c >> 27) & 15u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t slot = first + k;
                     float t, u, v;
                     if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
                         if (ANY) return true;
@@ -206,10 +225,26 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
                 }
             }
         }
-        if (!descend) {
-            if (sp == 0) break;
-            node = stack[--sp];
+        const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
+        if (i0 || i1) {
+            trail = (trail << 1) | ((i0 && i1) ? 1ull : 0ull);
+            node = (i0 && i1) ? (t0 <= t1 ? c0 : c1) : (i0 ? c0 : c1);
+            continue;
         }
+        // pop: climb until a level with a pending sibling
+        bool done = false;
+        while ((trail & 1ull) == 0ull) {
+            if (trail == 0ull) {
+                done = true;
+                break;
+            }
+            trail >>= 1;
+            node = nodes[node].parent;
+        }
+        if (done) break;
+        const uint32_t p = nodes[node].parent;
+        node = (nodes[p].c0 == node) ? nodes[p].c1 : nodes[p].c0;
+        trail ^= 1ull;
     }
     return found;
 }

@@ -29,6 +29,7 @@ struct UsArgs {
     uint32_t cap, n_paths, depth, seed;
     uint32_t ppr_pass, path_first;  // paths per ray in this pass, global index of local path 0
     uint32_t lds_bytes;
+    uint32_t stat_stride;
 };
 
 DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // CustomIntegrator.py:289-304
@@ -40,7 +41,7 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 }
 
 template <bool FIRST, int ACCEL>
-__global__ __launch_bounds__(SEG) void k_us_bounce(const UsArgs a) {
+__global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SEG / 256) void k_us_bounce(const UsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[SEG / 64];
     __shared__ uint32_t wave_seg[SEG / 64];
@@ -181,9 +182,11 @@ __global__ __launch_bounds__(SEG) void k_us_bounce(const UsArgs a) {
         a.seg_out[seg] = total;
         uint32_t ns = 0;
         for (uint32_t w = 0; w < SEG / 64; ++w) ns += wave_seg[w];
-        atomicAdd(&a.stats[0], (unsigned long long)ns);
-        atomicAdd(&a.stats[1], (unsigned long long)ns);  // one occlusion ray per shaded segment
-        atomicAdd(&a.stats[2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)], (unsigned long long)cnt_in);
+        unsigned long long *row = a.stats + seg;  // per-segment rows, see k_bounce
+        const size_t stride = a.stat_stride;
+        row[0] += ns;
+        row[stride] += ns;  // one occlusion ray per shaded segment
+        row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
     }
 }
 

@@ -216,7 +216,7 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);
-        if (bvh.max_depth > 30) {
+        if (bvh.max_depth > 60) {
             pbrt_scene_destroy(s);
             return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
         }
@@ -224,11 +224,14 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         for (uint32_t k = 0; k < d->n_prims; ++k) ordered[k] = d->prims[bvh.order[k]];
         UP(upload(s, ordered.data(), ordered.size(), &s->ds.prims));
         UP(upload(s, bvh.order.data(), bvh.order.size(), &s->ds.prim_ids));
+        std::vector<HostInner> inner;
+        to_inner_nodes(bvh, &inner);
+        static_assert(sizeof(HostInner) == sizeof(DevNode), "node layout");
         const DevNode *dn = nullptr;
-        UP(upload(s, reinterpret_cast<const DevNode *>(bvh.nodes.data()), bvh.nodes.size(), &dn));
+        UP(upload(s, reinterpret_cast<const DevNode *>(inner.data()), inner.size(), &dn));
         s->ds.nodes = dn;
-        s->ds.n_nodes = (uint32_t)bvh.nodes.size();
-        size_t lds = bvh.nodes.size() * sizeof(DevNode) + (size_t)d->n_prims * (sizeof(pbrt_prim) + 4);
+        s->ds.n_nodes = (uint32_t)inner.size();
+        size_t lds = inner.size() * sizeof(DevNode) + (size_t)d->n_prims * (sizeof(pbrt_prim) + 4);
         // static LDS of the bounce kernels: 3 * SEG/64 dwords; keep 1 KiB of slack
         if (c->lds_limit && lds + 1024 <= c->lds_limit) {
             s->accel_kernel = ACCEL_K_BVH_LDS;
@@ -339,10 +342,14 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
+    if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemsetAsync(acc, 0, film_px * 16, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     size_t n_ev = 0;
     uint32_t passes = 0, launches = 0;
@@ -352,7 +359,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.sc = s->ds;
         a.cam = *cam;
         a.Lhome = Lhome;
-        a.stats = dstats;
+        a.stats = segstats;
+    a.stat_stride = nseg;
         a.cap = cap;
         a.n_paths = (uint32_t)(npix_r * sc);
         a.max_depth = f->max_depth;
@@ -426,6 +434,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, nseg, (size_t)nseg, dstats);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0.0f;
@@ -490,6 +500,9 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
+    if (!segstats) return PBRT_E_NOMEM;
     float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
     if (!stA || !stB || !Lhome || !segA || !segB || !dstats || !io) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
@@ -497,13 +510,15 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipMemcpyAsync(io + 3 * (size_t)n, d, (size_t)n * 12, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 12, st));
     hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, n, io,
                        io + 3 * (size_t)n, io + 6 * (size_t)n);
     RadArgs a{};
     a.sc = s->ds;
     a.Lhome = Lhome;
-    a.stats = dstats;
+    a.stats = segstats;
+    a.stat_stride = nseg;
     a.cap = cap;
     a.n_paths = n;
     a.max_depth = max_depth;
@@ -622,6 +637,9 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
+    if (!segstats) return PBRT_E_NOMEM;
     float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
     if (!stA || !stB || !segA || !segB || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
@@ -632,11 +650,13 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const size_t nchan = (size_t)n_rays * T;
     HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     UsArgs a{};
     a.sc = s->ds;
     a.p = *p;
-    a.stats = dstats;
+    a.stats = segstats;
+    a.stat_stride = nseg;
     a.channel = d_channel;
     a.tx = d_tx;
     a.dir0 = d_dir;
@@ -692,6 +712,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, nseg, (size_t)nseg, dstats);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     float ms = 0.0f;

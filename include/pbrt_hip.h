@@ -226,6 +226,7 @@ typedef struct pbrt_stats {
     uint32_t passes;
     uint64_t model_bytes;  /* algorithmic HBM bytes of the last call (DESIGN.md byte model) */
     uint64_t bounce_model_bytes;
+    uint64_t live[16];     /* paths entering depth d (d = 0..15), summed over passes          */
 } pbrt_stats;
 
 typedef struct pbrt_ctx pbrt_ctx;

@@ -98,10 +98,13 @@ class UsReceiver(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("kernel_ms", C.c_double), ("bounce_ms", C.c_double), ("bounce_launches", C.c_uint32),
-                ("passes", C.c_uint32), ("model_bytes", C.c_uint64), ("bounce_model_bytes", C.c_uint64)]
+                ("passes", C.c_uint32), ("model_bytes", C.c_uint64), ("bounce_model_bytes", C.c_uint64),
+                ("live", C.c_uint64 * 16)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["live"] = list(self.live)
+        return d
 
 
 _P = C.c_void_p

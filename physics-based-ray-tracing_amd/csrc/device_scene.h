@@ -31,7 +31,7 @@ struct DevScene {
     const uint32_t *light_prims;  // caller's primitive indices
     const float *light_cdf;
     const pbrt_prim *prims_by_id;  // caller order (== prims for BRUTE); used by emitter sampling
-    uint32_t n_prims, n_nodes, n_emitters, n_mats;
+    uint32_t n_prims, n_nodes, n_emitters, n_mats, n_light_prims;
 };
 
 struct Hit {
@@ -439,7 +439,22 @@ struct ESample {
     bool delta, valid;
     uint32_t emitter;
 };
-DEV ESample sample_emitter(const DevScene &sc, V3 p, F4 u) {
+// The per-lane (gathered) scene tables of the shading code: global memory, or -- for brute-force
+// scenes, where every table has at most 32 entries -- copies staged into LDS by the workgroup.
+struct Tables {
+    const pbrt_prim *prims_by_slot;  // indexed by Hit::slot
+    const pbrt_prim *prims_by_id;    // indexed by the caller's primitive index (light_prims entries)
+    const pbrt_material *mats;
+    const pbrt_emitter *emitters;
+    const uint32_t *light_prims;
+    const float *light_cdf;
+    uint32_t n_emitters;
+};
+DEV Tables global_tables(const DevScene &sc) {
+    return {sc.prims, sc.prims_by_id, sc.mats, sc.emitters, sc.light_prims, sc.light_cdf, sc.n_emitters};
+}
+
+DEV ESample sample_emitter(const Tables &sc, V3 p, F4 u) {
     ESample e;
     e.valid = false;
     e.delta = false;

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
     }
     LdsScene ls = {nullptr, nullptr, nullptr};
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
+    __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
+    const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     const uint32_t cap = a.cap;
     const bool alive = tid < cnt_in;
     const uint32_t slot = base + tid;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
         Hit h;
         if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h)) {                 // :309-312
             did_seg = true;
-            const pbrt_prim &P = scene_prim<ACCEL>(a.sc, ls, h.slot);
+            const pbrt_prim &P = tb.prims_by_slot[h.slot];
             SI si = make_si(P, o, d, h.t, h.u, h.v);
             const float distance = h.t;                                                // :314
             geo_len += distance;                                                       // :315
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
             float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
             float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;           // :329
             float phase = a.two_pi_f * total_time;                                     // :330
-            const pbrt_material M = a.sc.mats[P.material];
+            const pbrt_material M = tb.mats[P.material];
             Frame fr = make_frame(si.n);
             V3 wi = to_local(fr, -d);
             float a_resp, bpdf;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void k_emitter_sample(DevScene sc, uint32_t n,
                                                         uint32_t *emitter) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    ESample e = sample_emitter(sc, v3(p[i], p[n + i], p[2 * n + i]), F4{u[i], u[n + i], u[2 * n + i], u[3 * n + i]});
+    ESample e = sample_emitter(global_tables(sc), v3(p[i], p[n + i], p[2 * n + i]), F4{u[i], u[n + i], u[2 * n + i], u[3 * n + i]});
     d[i] = e.d.x;
     d[n + i] = e.d.y;
     d[2 * n + i] = e.d.z;

@@ -206,13 +206,15 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     s->ds.n_emitters = d->n_emitters;
     UP(upload(s, d->light_prims, d->n_light_prims, &s->ds.light_prims));
     UP(upload(s, d->light_cdf, d->n_light_prims, &s->ds.light_cdf));
+    s->ds.n_light_prims = d->n_light_prims;
     const bool want_bvh = d->accel == PBRT_ACCEL_BVH || (d->accel == PBRT_ACCEL_AUTO && d->n_prims > 32);
     if (!want_bvh) {
         s->ds.prims = d_prims_by_id;
         s->ds.prim_ids = nullptr;
         s->ds.nodes = nullptr;
         s->ds.n_nodes = 0;
-        s->accel_kernel = ACCEL_K_BRUTE;
+        const bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
+        s->accel_kernel = small ? ACCEL_K_BRUTE : ACCEL_K_BRUTE_BIG;
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);
@@ -273,6 +275,9 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg) {
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        case ACCEL_K_BRUTE_BIG:
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG), 0, st, a);
             break;
         case ACCEL_K_BVH_GLOBAL:
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
@@ -456,6 +461,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     S.bounce_launches = launches;
     S.passes = passes;
     uint64_t tot, bb;
+    for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, &tot, &bb);
     S.model_bytes = tot;
     S.bounce_model_bytes = bb;
@@ -583,6 +589,9 @@ static void launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            break;
+        case ACCEL_K_BRUTE_BIG:
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG), 0, st, a);
             break;
         case ACCEL_K_BVH_GLOBAL:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
@@ -733,6 +742,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     S.bounce_ms = bounce_ms;
     S.bounce_launches = launches;
     S.passes = passes;
+    for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     uint64_t bb = 0;
     for (uint32_t d = 0; d < MAX_DEPTH_STATS; ++d) {
         uint64_t in = hstats[2 + d], next = d + 1 < MAX_DEPTH_STATS ? hstats[2 + d + 1] : 0;
@@ -829,7 +839,7 @@ int pbrt_ray_intersect(pbrt_scene *s, uint32_t n, const float *o, const float *d
     float *dO = S.in(o, 3 * (size_t)n), *dD = S.in(d, 3 * (size_t)n), *dT = S.in(tmax, n);
     float *rt = S.out<float>(n), *ru = S.out<float>(n), *rv = S.out<float>(n);
     uint32_t *rp = S.out<uint32_t>(n);
-    if (s->accel_kernel == ACCEL_K_BRUTE)
+    if (s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG)
         hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
     else
         hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
@@ -846,7 +856,7 @@ int pbrt_ray_test(pbrt_scene *s, uint32_t n, const float *o, const float *d, con
     LEAF_BEGIN(s->ctx, (size_t)n * 4 * 9);
     float *dO = S.in(o, 3 * (size_t)n), *dD = S.in(d, 3 * (size_t)n), *dT = S.in(tmax, n);
     uint8_t *rh = S.out<uint8_t>(n);
-    if (s->accel_kernel == ACCEL_K_BRUTE)
+    if (s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG)
         hipLaunchKernelGGL(k_ray_test<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
     else
         hipLaunchKernelGGL(k_ray_test<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);

@@ -43,10 +43,11 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 template <bool FIRST, int ACCEL>
 __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SEG / 256) void k_us_bounce(const UsArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-    __shared__ uint32_t wave_tot[SEG / 64];
-    __shared__ uint32_t wave_seg[SEG / 64];
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x, base = seg * SEG;
-    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, (uint32_t)SEG) : 0u) : a.seg_in[seg];
+    __shared__ uint32_t wave_tot[2][SEG / 64];
+    __shared__ uint32_t wave_seg[2][SEG / 64];
+    constexpr uint32_t REGION = us_region_segs(ACCEL) * SEG;
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x, base = seg * REGION;  // seg: region index (see k_bounce)
+    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, REGION) : 0u) : a.seg_in[seg];
     if (cnt_in == 0) {
         if (tid == 0) a.seg_out[seg] = 0;
         return;
@@ -55,10 +56,14 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
+    if (ACCEL == ACCEL_K_BRUTE) fill_tables_lds(a.sc, tab_lds);
     const uint32_t cap = a.cap;
-    const bool alive = tid < cnt_in;
-    const uint32_t slot = base + tid;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
+    uint32_t out_off = 0, ns_acc = 0;
+    for (uint32_t it0 = 0; it0 < cnt_in; it0 += SEG) {
+    const uint32_t buf = (it0 / SEG) & 1u;
+    const bool alive = it0 + tid < cnt_in;
+    const uint32_t slot = base + it0 + tid;
     bool survive = false, did_seg = false;
     V3 o, d;
     float amp, atten, tof, geo_len;
@@ -155,19 +160,19 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
     const unsigned long long bseg = __ballot(did_seg);
     if ((tid & 63) == 0) {
-        wave_tot[wid] = (uint32_t)__popcll(bal);
-        wave_seg[wid] = (uint32_t)__popcll(bseg);
+        wave_tot[buf][wid] = (uint32_t)__popcll(bal);
+        wave_seg[buf][wid] = (uint32_t)__popcll(bseg);
     }
     __syncthreads();
     uint32_t off = 0, total = 0;
 #pragma unroll
     for (uint32_t w = 0; w < SEG / 64; ++w) {
-        uint32_t t = wave_tot[w];
+        uint32_t t = wave_tot[buf][w];
         off += (w < wid) ? t : 0u;
         total += t;
     }
     if (survive) {
-        float *s = a.out + base + off + prefix;
+        float *s = a.out + base + out_off + off + prefix;
         s[0 * cap] = o.x;
         s[1 * cap] = o.y;
         s[2 * cap] = o.z;
@@ -180,14 +185,16 @@ __global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SE
         s[9 * cap] = geo_len;
         s[10 * cap] = __uint_as_float(home);
     }
+    out_off += total;
+    if (tid == 0)
+        for (uint32_t w = 0; w < SEG / 64; ++w) ns_acc += wave_seg[buf][w];
+    }  // chunk loop
     if (tid == 0) {
-        a.seg_out[seg] = total;
-        uint32_t ns = 0;
-        for (uint32_t w = 0; w < SEG / 64; ++w) ns += wave_seg[w];
-        unsigned long long *row = a.stats + seg;  // per-segment rows, see k_bounce
+        a.seg_out[seg] = out_off;
+        unsigned long long *row = a.stats + seg;  // per-region rows, see k_bounce
         const size_t stride = a.stat_stride;
-        row[0] += ns;
-        row[stride] += ns;  // one occlusion ray per shaded segment
+        row[0] += ns_acc;
+        row[stride] += ns_acc;  // one occlusion ray per shaded segment
         row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
     }
 }

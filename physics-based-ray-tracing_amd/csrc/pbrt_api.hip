@@ -338,8 +338,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (8u << 20);
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
     NEED(c, npix_r * s_pass < 0xfffffc00ull);
-    const uint32_t cap = div_up(npix_r * s_pass, SEG) * SEG;
-    const uint32_t nseg = cap / SEG;
+    const uint32_t REGION = rad_region_segs(s->accel_kernel) * SEG;
+    const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
+    const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
@@ -357,6 +358,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     size_t n_ev = 0;
+    hipEvent_t pass_e1 = nullptr;
     uint32_t passes = 0, launches = 0;
     for (uint32_t s0 = 0; s0 < f->spp; s0 += s_pass, ++passes) {
         const uint32_t sc = std::min(s_pass, f->spp - s0);
@@ -380,7 +382,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.film_w = W;
         a.film_h = H;
         a.lds_bytes = s->lds_bytes;
-        const uint32_t nseg_pass = div_up(a.n_paths, SEG);
+        const uint32_t nseg_pass = div_up(a.n_paths, REGION);
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
         for (uint32_t depth = 0; depth < f->max_depth; ++depth) {
@@ -389,15 +391,18 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             a.out = out;
             a.seg_in = sin;
             a.seg_out = sout;
-            hipEvent_t e0 = c->event(n_ev), e1 = c->event(n_ev + 1);
-            if (!e0 || !e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
-            n_ev += 2;
-            HIPCHK(c, hipEventRecord(e0, st));
+            // ONE event pair per pass around its bounce launches (a pair per launch costs ~8 us of queue bubbles each)
+            if (depth == 0) {
+                pass_e1 = c->event(n_ev + 1);
+                hipEvent_t e0 = c->event(n_ev);
+                if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+                n_ev += 2;
+                HIPCHK(c, hipEventRecord(e0, st));
+            }
             if (depth == 0)
                 launch_bounce<true>(s, a, nseg_pass);
             else
                 launch_bounce<false>(s, a, nseg_pass);
-            HIPCHK(c, hipEventRecord(e1, st));
             HIPCHK(c, hipGetLastError());
             ++launches;
             std::swap(in, out);
@@ -412,6 +417,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 if (live == 0) break;
             }
         }
+        HIPCHK(c, hipEventRecord(pass_e1, st));
         FilmArgs fa{};
         fa.Lhome = Lhome;
         fa.acc = acc;
@@ -499,7 +505,8 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
-    const uint32_t cap = div_up(n, SEG) * SEG, nseg = cap / SEG;
+    const uint32_t REGION = rad_region_segs(s->accel_kernel) * SEG;
+    const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
@@ -518,7 +525,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
     HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 12, st));
-    hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, n, io,
+    hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, REGION, n, io,
                        io + 3 * (size_t)n, io + 6 * (size_t)n);
     RadArgs a{};
     a.sc = s->ds;
@@ -640,7 +647,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const uint64_t pass_paths = 8u << 20;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
-    const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, SEG) * SEG, nseg = cap / SEG;
+    const uint32_t REGION = us_region_segs(s->accel_kernel) * SEG;
+    const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
@@ -686,13 +694,14 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     a.seed = seed;
     a.lds_bytes = s->lds_bytes;
     size_t n_ev = 0;
+    hipEvent_t pass_e1 = nullptr;
     uint32_t passes = 0, launches = 0;
     for (uint32_t k0 = 0; k0 < ppr; k0 += ppr_pass, ++passes) {
         const uint32_t kc = std::min(ppr_pass, ppr - k0);
         a.ppr_pass = kc;
         a.path_first = path_offset + k0;
         a.n_paths = n_rays * kc;
-        const uint32_t nseg_pass = div_up(a.n_paths, SEG);
+        const uint32_t nseg_pass = div_up(a.n_paths, REGION);
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
         for (uint32_t depth = 0; depth < p->max_depth; ++depth) {
@@ -701,20 +710,24 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
             a.out = out;
             a.seg_in = sin;
             a.seg_out = sout;
-            hipEvent_t e0 = c->event(n_ev), e1 = c->event(n_ev + 1);
-            if (!e0 || !e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
-            n_ev += 2;
-            HIPCHK(c, hipEventRecord(e0, st));
+            // ONE event pair per pass around its bounce launches (a pair per launch costs ~8 us of queue bubbles each)
+            if (depth == 0) {
+                pass_e1 = c->event(n_ev + 1);
+                hipEvent_t e0 = c->event(n_ev);
+                if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+                n_ev += 2;
+                HIPCHK(c, hipEventRecord(e0, st));
+            }
             if (depth == 0)
                 launch_us<true>(s, a, nseg_pass);
             else
                 launch_us<false>(s, a, nseg_pass);
-            HIPCHK(c, hipEventRecord(e1, st));
             HIPCHK(c, hipGetLastError());
             ++launches;
             std::swap(in, out);
             std::swap(sin, sout);
         }
+        HIPCHK(c, hipEventRecord(pass_e1, st));
     }
     const float inv_norm = 1.0f / (float)(norm_paths ? norm_paths : 1);
     hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);

@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-spp", type=int, default=0, help="0: pick the largest power of two <= 256 that takes about 15 s")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(visible cores, 64)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the gather runs over gloo "
+                         "(host staging); exercises sharding + stitching, NOT RCCL -- numbers are not benchmark numbers")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -54,6 +57,8 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     os.environ["PBRT_DEVICE"] = str(local_rank)
 
     import numpy as np
@@ -66,7 +71,10 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     mi = importlib.import_module("physics-based-ray-tracing_amd")
     par = importlib.import_module("physics-based-ray-tracing_amd.parallel")
@@ -84,6 +92,8 @@ def main():
 
     def step():
         tile, layout = par.render_tiles(scene, spp, seed, rank, world, band_rows, device=device)
+        if args.rehearse_on_one_gpu and world > 1:
+            tile = tile.cpu()  # gloo gathers host tensors
         film = par.gather_film(tile, layout, RES, RES, rank, world)
         return film, tile
 
@@ -107,7 +117,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -139,6 +149,11 @@ def main():
                          "avg_launch_ms": round(bounce_ms / max(launches, 1), 5), "launches": launches,
                          "kernel_ms_per_step": round(kernel_ms / args.steps, 3)},
         }
+        if args.rehearse_on_one_gpu and world > 1:
+            # the stitched film of the sharded job must equal the un-sharded render bit for bit
+            whole = scene.integrator().render(scene, seed=seed, spp=spp)
+            out["rehearsal"] = {"backend": "gloo", "ranks_on_device_0": world,
+                                "stitched_equals_unsharded": bool(np.array_equal(film.cpu().numpy(), whole))}
         if world == 1 and not args.no_cpu_baseline:
             from oracle import binding as ob
             cores = args.cpu_threads or min(len(os.sched_getaffinity(0)), 64)

@@ -437,7 +437,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         fa.film_h = H;
         fa.filter = f->filter;
         fa.seed = f->seed;
-        hipLaunchKernelGGL(k_film_accum, dim3(div_up(film_px, 256)), dim3(256), 0, st, fa);
+        if (f->filter == PBRT_FILTER_BOX)
+            hipLaunchKernelGGL(k_film_accum, dim3(div_up(film_px, 256)), dim3(256), 0, st, fa);
+        else
+            hipLaunchKernelGGL(k_film_accum_tiled, dim3(div_up(f->crop_w, FILM_TILE), div_up(f->crop_h, FILM_TILE)),
+                               dim3(FILM_TILE, FILM_TILE), 0, st, fa);
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_film_resolve, dim3(div_up(film_px, 256)), dim3(256), 0, st, acc, (float *)d_out, (uint32_t)film_px,

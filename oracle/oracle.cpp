@@ -46,6 +46,7 @@ struct Scene {
     std::vector<uint32_t> light_prims;
     std::vector<float> light_cdf;
     bool use_bvh = false;
+    std::vector<pbrt_prim> occ;  // brute-force scenes: primitives that can occlude a segment (find_occluders)
     std::vector<BvhNode> nodes;
     std::vector<uint32_t> order;
 };
@@ -241,6 +242,62 @@ bool any_hit(const Scene &sc, V3 o, V3 d, float tmax) {
         }
     }
     return false;
+}
+
+// Next-event shadow rays are SEGMENTS between two points of the scene.  In brute-force scenes they are
+// tested against Scene::occ only: every primitive except the planar ones that lie on a supporting plane of
+// the scene's convex hull (all other geometry and every point emitter in one closed half-space of their
+// plane) -- a segment whose end points are in the hull cannot cross those (DESIGN.md "Intersection").
+// Unbounded occlusion rays (ultrasound mode, CustomIntegrator.py:324) always test every primitive.
+bool any_hit_segment(const Scene &sc, V3 o, V3 d, float tmax) {
+    if (sc.use_bvh) return any_hit(sc, o, d, tmax);
+    for (const pbrt_prim &P : sc.occ) {
+        float num, den, us, vs;
+        if (prim_candidate(P, o, d, tmax, &num, &den, &us, &vs)) return true;
+    }
+    return false;
+}
+
+void find_occluders(Scene &sc) {
+    sc.occ.clear();
+    for (size_t i = 0; i < sc.prims.size(); ++i) {
+        const pbrt_prim &P = sc.prims[i];
+        bool keep = true;
+        if (P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM) {
+            const double n[3] = {P.g[9], P.g[10], P.g[11]}, p0[3] = {P.g[0], P.g[1], P.g[2]};
+            double lo = INFINITY, hi = -INFINITY;
+            auto side = [&](double x, double y, double z) { return n[0] * (x - p0[0]) + n[1] * (y - p0[1]) + n[2] * (z - p0[2]); };
+            auto acc = [&](double s) {
+                lo = std::min(lo, s);
+                hi = std::max(hi, s);
+            };
+            for (size_t j = 0; j < sc.prims.size(); ++j) {
+                if (j == i) continue;
+                const pbrt_prim &Q = sc.prims[j];
+                if (Q.type == PBRT_PRIM_SPHERE) {
+                    double s = side(Q.g[0], Q.g[1], Q.g[2]);
+                    acc(s - (double)Q.g[3]);
+                    acc(s + (double)Q.g[3]);
+                } else {
+                    const double v0[3] = {Q.g[0], Q.g[1], Q.g[2]}, e1[3] = {Q.g[3], Q.g[4], Q.g[5]}, e2[3] = {Q.g[6], Q.g[7], Q.g[8]};
+                    acc(side(v0[0], v0[1], v0[2]));
+                    acc(side(v0[0] + e1[0], v0[1] + e1[1], v0[2] + e1[2]));
+                    acc(side(v0[0] + e2[0], v0[1] + e2[1], v0[2] + e2[2]));
+                    if (Q.type == PBRT_PRIM_PARALLELOGRAM)
+                        acc(side(v0[0] + e1[0] + e2[0], v0[1] + e1[1] + e2[1], v0[2] + e1[2] + e2[2]));
+                }
+            }
+            for (const pbrt_emitter &E : sc.emitters)
+                if (E.type == PBRT_EMIT_POINT) acc(side(E.pos[0], E.pos[1], E.pos[2]));
+            if (lo >= 0.0 || hi <= 0.0) keep = false;
+            // a scene lit by ONE single-primitive area light: every shadow segment ends (1 - ShadowEpsilon)
+            // short of that primitive's plane, so the light itself never occludes
+            if (sc.emitters.size() == 1 && sc.emitters[0].type == PBRT_EMIT_AREA && sc.emitters[0].count == 1 &&
+                sc.light_prims[sc.emitters[0].first] == i)
+                keep = false;
+        }
+        if (keep) sc.occ.push_back(P);
+    }
 }
 
 void prim_bounds(const pbrt_prim &P, float lo[3], float hi[3]) {
@@ -686,7 +743,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
                     float sd = sqrtf(dot(sv, sv));
                     V3 sdir = sv * (1.0f / sd);
                     if (st) st->shadow++;
-                    if (!any_hit(sc, so, sdir, sd * (1.0f - kShadowEps))) {
+                    if (!any_hit_segment(sc, so, sdir, sd * (1.0f - kShadowEps))) {
                         float mis = es.delta ? 1.0f : mis_weight(es.pdf, bpdf);
                         L = {fmaf(thr.x * f.x, es.weight.x * mis, L.x), fmaf(thr.y * f.y, es.weight.y * mis, L.y),
                              fmaf(thr.z * f.z, es.weight.z * mis, L.z)};
@@ -766,7 +823,10 @@ int oracle_scene_create(const pbrt_scene_desc *desc, oracle_scene **out) {
         }
     }
     s->sc.use_bvh = desc->accel == PBRT_ACCEL_BVH || (desc->accel == PBRT_ACCEL_AUTO && desc->n_prims > 32);
-    if (s->sc.use_bvh) build_bvh(s->sc);
+    if (s->sc.use_bvh)
+        build_bvh(s->sc);
+    else
+        find_occluders(s->sc);
     *out = s;
     return PBRT_OK;
 }

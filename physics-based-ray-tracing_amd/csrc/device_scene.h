@@ -31,6 +31,13 @@ struct DevScene {
     const uint32_t *light_prims;  // caller's primitive indices
     const float *light_cdf;
     const pbrt_prim *prims_by_id;  // caller order (== prims for BRUTE); used by emitter sampling
+    // BRUTE only: the primitives that can occlude a SEGMENT between two points of the scene (copies, any
+    // order).  Planar primitives on a supporting plane of the scene's convex hull (all other geometry and
+    // every point emitter on one side) can never be crossed by such a segment and are left out, e.g. the
+    // five walls of the Cornell box (pbrt_api.hip: find_occluders).  Unbounded occlusion rays (ultrasound
+    // mode, pbrt_ray_test) always walk the full list.
+    const pbrt_prim *occ_prims;
+    uint32_t n_occ;
     uint32_t n_prims, n_nodes, n_emitters, n_mats, n_light_prims;
 };
 
@@ -104,17 +111,20 @@ DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u
 // Candidates are ratios t = num / den (den > 0): the range test is ts <= tmax * det, candidates are
 // ranked by cross-multiplication and the one division happens after the loop, so the loop body of a
 // triangle / parallelogram is straight-line code (selects, no divergent branch, no division).
-template <bool ANY>
+template <bool ANY, bool SEGMENT = false>
 DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     bool found = false;
     float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bp = 0xffffffffu;
+    const pbrt_prim *list = (ANY && SEGMENT) ? sc.occ_prims : sc.prims;
+    const uint32_t n_list = (ANY && SEGMENT) ? sc.n_occ : sc.n_prims;
+    if (n_list == 0) return false;
     // software pipeline over the (wave-uniform) primitive records: the 64-byte scalar load of primitive
     // i + 1 is in flight while primitive i is tested
-    pbrt_prim nxt = sc.prims[0];
-    for (uint32_t i = 0; i < sc.n_prims; ++i) {
+    pbrt_prim nxt = list[0];
+    for (uint32_t i = 0; i < n_list; ++i) {
         const pbrt_prim P = nxt;
-        nxt = sc.prims[min(i + 1, sc.n_prims - 1)];
+        nxt = list[min(i + 1, n_list - 1)];
         const uint32_t type = P.type;  // wave-uniform
         bool ok;
         float num, den, us, vs;

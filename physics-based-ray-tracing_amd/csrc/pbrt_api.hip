@@ -100,6 +100,57 @@ static int upload(pbrt_scene *s, const T *src, size_t n, const T **dst) {
 
 static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// Primitives that can occlude a segment between two points of the scene (DevScene::occ_prims).  A planar
+// primitive is dropped when all OTHER geometry and every point emitter lie in one closed half-space of its
+// plane: it then sits on the boundary of the scene's convex hull and a segment whose end points are in the
+// hull cannot cross it.  Exact comparisons (>= 0 in f64 on the f32 data), so nearly-coplanar scenes just
+// keep their primitives.
+static std::vector<pbrt_prim> find_occluders(const pbrt_scene_desc *d) {
+    std::vector<pbrt_prim> occ;
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const pbrt_prim &P = d->prims[i];
+        bool keep = true;
+        if (P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM) {
+            const double n[3] = {P.g[9], P.g[10], P.g[11]}, p0[3] = {P.g[0], P.g[1], P.g[2]};
+            double lo = INFINITY, hi = -INFINITY;
+            auto side = [&](double x, double y, double z) {
+                return n[0] * (x - p0[0]) + n[1] * (y - p0[1]) + n[2] * (z - p0[2]);
+            };
+            auto acc = [&](double s) {
+                lo = std::min(lo, s);
+                hi = std::max(hi, s);
+            };
+            for (uint32_t j = 0; j < d->n_prims; ++j) {
+                if (j == i) continue;
+                const pbrt_prim &Q = d->prims[j];
+                if (Q.type == PBRT_PRIM_SPHERE) {
+                    double s = side(Q.g[0], Q.g[1], Q.g[2]);
+                    acc(s - (double)Q.g[3]);
+                    acc(s + (double)Q.g[3]);
+                } else {
+                    const double v0[3] = {Q.g[0], Q.g[1], Q.g[2]}, e1[3] = {Q.g[3], Q.g[4], Q.g[5]}, e2[3] = {Q.g[6], Q.g[7], Q.g[8]};
+                    acc(side(v0[0], v0[1], v0[2]));
+                    acc(side(v0[0] + e1[0], v0[1] + e1[1], v0[2] + e1[2]));
+                    acc(side(v0[0] + e2[0], v0[1] + e2[1], v0[2] + e2[2]));
+                    if (Q.type == PBRT_PRIM_PARALLELOGRAM)
+                        acc(side(v0[0] + e1[0] + e2[0], v0[1] + e1[1] + e2[1], v0[2] + e1[2] + e2[2]));
+                }
+            }
+            for (uint32_t e = 0; e < d->n_emitters; ++e)
+                if (d->emitters[e].type == PBRT_EMIT_POINT)
+                    acc(side(d->emitters[e].pos[0], d->emitters[e].pos[1], d->emitters[e].pos[2]));
+            if (lo >= 0.0 || hi <= 0.0) keep = false;
+            // a scene lit by ONE single-primitive area light: every shadow segment ends (1 - ShadowEpsilon)
+            // short of that primitive's plane, so the light itself never occludes
+            if (d->n_emitters == 1 && d->emitters[0].type == PBRT_EMIT_AREA && d->emitters[0].count == 1 &&
+                d->light_prims[d->emitters[0].first] == i)
+                keep = false;
+        }
+        if (keep) occ.push_back(P);
+    }
+    return occ;
+}
+
 extern "C" {
 
 int pbrt_abi_version(void) { return PBRT_ABI_VERSION; }
@@ -215,6 +266,9 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         s->ds.n_nodes = 0;
         const bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
         s->accel_kernel = small ? ACCEL_K_BRUTE : ACCEL_K_BRUTE_BIG;
+        std::vector<pbrt_prim> occ = find_occluders(d);
+        UP(upload(s, occ.data(), occ.size(), &s->ds.occ_prims));
+        s->ds.n_occ = (uint32_t)occ.size();
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);

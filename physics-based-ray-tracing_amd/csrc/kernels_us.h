@@ -41,7 +41,8 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 }
 
 template <bool FIRST, int ACCEL>
-__global__ __launch_bounds__(SEG, ACCEL == ACCEL_K_BRUTE ? SEG_WAVES_PER_EU : SEG / 256) void k_us_bounce(const UsArgs a) {
+__global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
+    constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];
     __shared__ uint32_t wave_seg[2][SEG / 64];

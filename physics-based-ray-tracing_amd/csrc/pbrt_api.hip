@@ -328,16 +328,16 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BRUTE_BIG:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BVH_GLOBAL:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
             break;
         default:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG), s->lds_bytes, st, a);
+            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
             break;
     }
 }
@@ -392,7 +392,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (8u << 20);
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
     NEED(c, npix_r * s_pass < 0xfffffc00ull);
-    const uint32_t REGION = rad_region_segs(s->accel_kernel) * SEG;
+    const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
     const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
@@ -563,7 +563,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
-    const uint32_t REGION = rad_region_segs(s->accel_kernel) * SEG;
+    const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
@@ -653,16 +653,16 @@ static void launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BRUTE_BIG:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BVH_GLOBAL:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG), 0, st, a);
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
             break;
         default:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG), s->lds_bytes, st, a);
+            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
             break;
     }
 }
@@ -705,7 +705,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const uint64_t pass_paths = 8u << 20;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
-    const uint32_t REGION = us_region_segs(s->accel_kernel) * SEG;
+    const uint32_t REGION = us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);

@@ -149,11 +149,13 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
             us = neg ? -us : us;
             vs = neg ? -vs : vs;
             ts = neg ? -ts : ts;
-            ok = (det > 0.0f) & (us >= 0.0f) & (vs >= 0.0f) & (ts >= 0.0f) & (ts <= tmax * det);
+            // (us >= 0 & vs >= 0 & ts >= 0) and (us <= det & vs <= det) folded into min3 / max: same truth
+            // value for finite operands (all operands are finite here), three compares less per primitive
+            ok = (det > 0.0f) & (fminf(fminf(us, vs), ts) >= 0.0f) & (ts <= tmax * det);
             if (type == PBRT_PRIM_TRIANGLE)
                 ok = ok & (us + vs <= det);
             else
-                ok = ok & (us <= det) & (vs <= det);
+                ok = ok & (fmaxf(us, vs) <= det);
             num = ts;
             den = det;
         }

@@ -395,6 +395,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
     const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
+    NEED(c, (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the state arrays are addressed through 32-bit buffer offsets
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);

@@ -140,7 +140,7 @@ def main():
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"cbox.xml {RES}x{RES}, {SPP_PER_GPU} spp per GPU (spp={spp}), path max_depth {MAX_DEPTH}, "
-                                   f"tent filter, 12 triangles + 2 spheres; film in interleaved {band_rows}-row bands, one gather",
+                                   f"tent filter, 6 analytic quads + 2 spheres; film in interleaved {band_rows}-row bands, one gather",
                        "samples_per_step": total_samples, "seed": seed,
                        "mean_segments_per_sample": round(segments / max(samples, 1), 4)},
             "roofline": {"bound": "hbm", "kernel": "k_bounce", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

@@ -111,20 +111,38 @@ DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u
 // Candidates are ratios t = num / den (den > 0): the range test is ts <= tmax * det, candidates are
 // ranked by cross-multiplication and the one division happens after the loop, so the loop body of a
 // triangle / parallelogram is straight-line code (selects, no divergent branch, no division).
+// The records are read through the constant address space: a uniform load from it is always selected as
+// s_load, independent of the compiler's "is this memory clobbered earlier in the kernel" analysis (any barrier,
+// fence or inline asm ahead of the loop would otherwise turn the 16 dwords of every record into per-lane
+// global loads held in 16 VGPRs).  The scene is immutable while a kernel runs, so the promise holds.
+DEV pbrt_prim load_prim_uniform(const pbrt_prim *p) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    typedef const u32x4 __attribute__((address_space(4))) *cptr;
+    struct Raw {
+        u32x4 q[4];
+    };
+    static_assert(sizeof(Raw) == sizeof(pbrt_prim), "pbrt_prim is 16 dwords");
+    cptr q = (cptr)(uintptr_t)p;
+    Raw r = {{q[0], q[1], q[2], q[3]}};
+    return __builtin_bit_cast(pbrt_prim, r);
+}
+
 template <bool ANY, bool SEGMENT = false>
 DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     bool found = false;
     float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
     uint32_t bp = 0xffffffffu;
     const pbrt_prim *list = (ANY && SEGMENT) ? sc.occ_prims : sc.prims;
-    const uint32_t n_list = (ANY && SEGMENT) ? sc.n_occ : sc.n_prims;
+    // readfirstlane: keeps the loop counter and the record address in SGPRs (s_min / s_lshl / s_add) -- without it
+    // the compiler carries n_list - 1 in a VGPR and spends 5 VALU + 2 readfirstlane per record on the address
+    const uint32_t n_list = (uint32_t)__builtin_amdgcn_readfirstlane((int)((ANY && SEGMENT) ? sc.n_occ : sc.n_prims));
     if (n_list == 0) return false;
     // software pipeline over the (wave-uniform) primitive records: the 64-byte scalar load of primitive
     // i + 1 is in flight while primitive i is tested
-    pbrt_prim nxt = list[0];
+    pbrt_prim nxt = load_prim_uniform(list);
     for (uint32_t i = 0; i < n_list; ++i) {
         const pbrt_prim P = nxt;
-        nxt = list[min(i + 1, n_list - 1)];
+        nxt = load_prim_uniform(list + min(i + 1, n_list - 1));
         const uint32_t type = P.type;  // wave-uniform
         bool ok;
         float num, den, us, vs;

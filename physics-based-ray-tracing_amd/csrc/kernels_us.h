@@ -57,7 +57,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
-    if (ACCEL == ACCEL_K_BRUTE) fill_tables_lds(a.sc, tab_lds);
+    if (ACCEL == ACCEL_K_BRUTE) fill_tables_lds(a.sc, tab_lds, blockDim.x);
     const uint32_t cap = a.cap;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
     uint32_t out_off = 0, ns_acc = 0;

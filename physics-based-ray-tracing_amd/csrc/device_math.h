@@ -12,6 +12,44 @@
 
 #define DEV __device__ __forceinline__
 
+// Exact unsigned division by a launch-uniform divisor (Granlund-Montgomery round-up multiplier, the
+// branch-free 33-bit form):  n / d == (((n - hi) >> 1) + hi) >> shift  with hi = mulhi(n, magic), for every
+// 32-bit n and d >= 2; d == 1 is flagged.  5 VALU instead of the ~20 of a division by a runtime value.
+struct FastDiv {
+    uint32_t magic, shift, is_one, pad;
+};
+inline FastDiv make_fastdiv(uint32_t d) {  // host
+    FastDiv f = {0, 0, 0, 0};
+    if (d <= 1) {
+        f.is_one = 1;
+        return f;
+    }
+    uint32_t L = 31;
+    while (!(d >> L)) --L;  // floor(log2 d)
+    if ((d & (d - 1)) == 0) {
+        f.shift = L - 1;  // magic 0: ((n - 0) >> 1) >> (L - 1)
+        return f;
+    }
+    const uint64_t num = 1ull << (32 + L);
+    uint64_t m = num / d;
+    const uint64_t rem = num % d;
+    m += m;
+    if (2 * rem >= d) m += 1;
+    f.magic = (uint32_t)(m + 1);
+    f.shift = L;
+    return f;
+}
+inline uint32_t udiv_fast_host(uint32_t n, FastDiv f) {
+    if (f.is_one) return n;
+    const uint32_t hi = (uint32_t)(((uint64_t)n * f.magic) >> 32);
+    return (((n - hi) >> 1) + hi) >> f.shift;
+}
+DEV uint32_t udiv_fast(uint32_t n, FastDiv f) {
+    const uint32_t hi = __umulhi(n, f.magic);
+    const uint32_t q = (((n - hi) >> 1) + hi) >> f.shift;
+    return f.is_one ? n : q;
+}
+
 struct V3 {
     float x, y, z;
 };

@@ -398,7 +398,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     NEED(c, (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the state arrays are addressed through 32-bit buffer offsets
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
-    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
+    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
     float *acc = (float *)c->buf("film_acc", film_px * 16);
@@ -433,6 +433,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.ry0 = ry0;
         a.rw = rw;
         a.npix_r = (uint32_t)npix_r;
+        a.div_npix = make_fastdiv(a.npix_r);
+        a.div_rw = make_fastdiv(rw);
+        for (uint32_t n : {0u, 1u, rw - 1, rw, rw + 1, a.npix_r - 1, a.npix_r, a.npix_r + 1, cap - 1, cap, 0xffffffffu}) {
+            NEED(c, udiv_fast_host(n, a.div_npix) == n / a.npix_r && udiv_fast_host(n, a.div_rw) == n / rw);
+        }
         a.s_first = f->sample_offset + s0;
         a.film_w = W;
         a.film_h = H;
@@ -568,7 +573,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
-    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 3 * 4);
+    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
@@ -583,7 +588,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
     HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
-    HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 12, st));
+    HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 16, st));
     hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, REGION, n, io,
                        io + 3 * (size_t)n, io + 6 * (size_t)n);
     RadArgs a{};
@@ -599,6 +604,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     a.key_mode = 1;
     a.npix_r = 1;
     a.rw = 1;
+    a.div_npix = a.div_rw = make_fastdiv(1);
     a.index_offset = index_offset;
     a.sample_index = sample_index;
     a.lds_bytes = s->lds_bytes;
@@ -624,8 +630,10 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         }
     }
     HIPCHK(c, hipStreamSynchronize(st));
-    for (int k = 0; k < 3; ++k)
-        HIPCHK(c, hipMemcpy(rgb + (size_t)k * n, Lhome + (size_t)k * cap, (size_t)n * 4, hipMemcpyDeviceToHost));
+    std::vector<float> rec((size_t)n * 4);
+    HIPCHK(c, hipMemcpy(rec.data(), Lhome, (size_t)n * 16, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) rgb[(size_t)k * n + i] = rec[(size_t)i * 4 + k];
     return PBRT_OK;
 }
 

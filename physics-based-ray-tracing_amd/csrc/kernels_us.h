@@ -40,8 +40,20 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
     return alpha <= am ? 1.0f : (alpha <= ac ? mid : 0.0f);
 }
 
+// waves per SIMD the register allocator aims for: the ultrasound bounce (GGX sampling, expf / sinf / acosf) needs
+// about 95 VGPRs and spills 110 bytes per lane at the radiance kernel's 8 waves (64 VGPRs) -- measured, the spilling
+// build is still the fastest (8 waves 2.83 ms, 6 waves 2.98, 4 waves 3.06 on Sphere_Box 5 x 64 x 65536)
+#define US_AGG_LOG2 8
+#define US_AGG_BINS (1u << US_AGG_LOG2)
+#ifndef US_WAVES_PER_EU
+#define US_WAVES_PER_EU 8
+#endif
+__host__ __device__ constexpr uint32_t us_waves_per_eu(int accel) {
+    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? seg_waves_per_eu(accel) : US_WAVES_PER_EU;
+}
+
 template <bool FIRST, int ACCEL>
-__global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
+__global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];
@@ -57,7 +69,21 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
-    if (ACCEL == ACCEL_K_BRUTE) fill_tables_lds(a.sc, tab_lds, blockDim.x);
+    // Echo aggregation: the paths of a workgroup belong to few (angle, element) rays -- at the first bounce to ONE
+    // ray whose paths all hit the same point, so 4096 echoes land on <= n_elements channel-buffer words.  Global
+    // float atomics on the same word serialise in L2 (measured: 64 % of the kernel).  Echoes are therefore summed
+    // in a small LDS table keyed by the channel index (ds_cmpst claims a bin, ds_add_f32 adds); a bin owned by
+    // another index falls back to the global atomic; one global atomic per used bin when the workgroup is done.
+    __shared__ uint32_t agg_idx[US_AGG_BINS];
+    __shared__ float agg_sum[US_AGG_BINS];
+    for (uint32_t t = threadIdx.x; t < US_AGG_BINS; t += blockDim.x) {
+        agg_idx[t] = 0xffffffffu;
+        agg_sum[t] = 0.0f;
+    }
+    if (ACCEL == ACCEL_K_BRUTE)
+        fill_tables_lds(a.sc, tab_lds, blockDim.x);  // ends with the barrier that also publishes the empty bins
+    else
+        __syncthreads();
     const uint32_t cap = a.cap;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
     uint32_t out_off = 0, ns_acc = 0;
@@ -144,8 +170,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
                 float pressure = atten * amp * fd * sinf(phase);                       // :348
                 float tf = rintf(total_time * a.p.fs);                                 // :351-352
                 if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
-                if (tf >= 0.0f && tf < (float)T && visible)                            // :353
-                    atomicAdd(&a.channel[((size_t)ang * NE + recv) * T + (size_t)tf], pressure);  // :354
+                if (tf >= 0.0f && tf < (float)T && visible) {                          // :353
+                    const uint32_t ci = (ang * NE + recv) * T + (uint32_t)tf;          // :354 (host checks it fits 32 bits)
+#ifdef PBRT_ABLATE_US_AGG  // diagnostic builds only
+                    atomicAdd(&a.channel[ci], pressure);
+#else
+                    const uint32_t bin = (ci * 2654435761u) >> (32 - US_AGG_LOG2);
+                    const uint32_t owner = atomicCAS(&agg_idx[bin], 0xffffffffu, ci);
+                    if (owner == 0xffffffffu || owner == ci)
+                        __hip_atomic_fetch_add(&agg_sum[bin], pressure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else
+                        atomicAdd(&a.channel[ci], pressure);
+#endif
+                }
                 d = normalize(new_dir);                                                // :358-359
                 o = offset_origin(si.p, si.n, d);
                 float rr_prob = fminf(fabsf(atten * amp), 1.0f);                       // :364
@@ -190,6 +227,11 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     if (tid == 0)
         for (uint32_t w = 0; w < SEG / 64; ++w) ns_acc += wave_seg[buf][w];
     }  // chunk loop
+    __syncthreads();  // all echoes of the workgroup are in the bins
+    for (uint32_t t = tid; t < US_AGG_BINS; t += SEG) {
+        const uint32_t ci = agg_idx[t];
+        if (ci != 0xffffffffu) atomicAdd(&a.channel[ci], agg_sum[t]);
+    }
     if (tid == 0) {
         a.seg_out[seg] = out_off;
         unsigned long long *row = a.stats + seg;  // per-region rows, see k_bounce

@@ -683,6 +683,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     pbrt_ctx *c = s->ctx;
     NEED(c, p && d_channel);
     NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
+    NEED(c, (uint64_t)p->n_angles * p->n_elements * p->time_samples < 0xffffffffull);  // channel index is 32-bit (echo bins)
     NEED(c, p->max_depth > 0 && ppr > 0 && p->sound_speed > 0 && p->fs > 0);
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);

@@ -152,9 +152,14 @@ inline bool prim_candidate(const pbrt_prim &P, V3 o, V3 d, float tmax, float *nu
 }
 
 inline bool box_hit(const BvhNode &n, V3 o, V3 inv_d, float tbest) {
-    float tx0 = (n.lo[0] - o.x) * inv_d.x, tx1 = (n.hi[0] - o.x) * inv_d.x;
-    float ty0 = (n.lo[1] - o.y) * inv_d.y, ty1 = (n.hi[1] - o.y) * inv_d.y;
-    float tz0 = (n.lo[2] - o.z) * inv_d.z, tz1 = (n.hi[2] - o.z) * inv_d.z;
+    // the slabs are widened a little: a ray with a zero direction component whose origin lies exactly in a box
+    // face (0 * inf = NaN) must not be culled -- e.g. the probe axis through the centre vertex of a cone's base fan
+    const float px = 1e-6f * (1.0f + fmaxf(fabsf(n.lo[0]), fabsf(n.hi[0])));
+    const float py = 1e-6f * (1.0f + fmaxf(fabsf(n.lo[1]), fabsf(n.hi[1])));
+    const float pz = 1e-6f * (1.0f + fmaxf(fabsf(n.lo[2]), fabsf(n.hi[2])));
+    float tx0 = (n.lo[0] - px - o.x) * inv_d.x, tx1 = (n.hi[0] + px - o.x) * inv_d.x;
+    float ty0 = (n.lo[1] - py - o.y) * inv_d.y, ty1 = (n.hi[1] + py - o.y) * inv_d.y;
+    float tz0 = (n.lo[2] - pz - o.z) * inv_d.z, tz1 = (n.hi[2] + pz - o.z) * inv_d.z;
     float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tbest));
     // conservative slack so that the box test can never cull a primitive hit the brute-force loop

@@ -239,10 +239,33 @@ class RectangleShape(Shape):
 
 
 class ConeShape(Shape):
-    """'cone' (MitsubaScenes/Cone_*.xml) has no Mitsuba-3 definition; SURVEY.md section 8 f-4 (next)."""
+    """'cone' (MitsubaScenes/Cone_Box.xml:36-47, Cone_FLoating.xml) has no Mitsuba-3 definition.
+    [DEFINE]: the closed unit cone -- apex (0, 0, 1), base disc of radius 1
+    in the plane z = 0 -- under to_world, tessellated on the host into `segments` lateral triangles plus a
+    `segments`-triangle base fan (outward face normals), so it takes the BVH path like any other mesh and
+    non-uniform to_world scales (Cone_Box.xml: 0.06 / 0.06 / 0.10) need no special case."""
+
+    def __init__(self, props):
+        super().__init__(props)
+        self.segments = int(props.get("segments", 96))
+        if self.segments < 3:
+            raise ValueError("cone: segments must be >= 3")
 
     def primitives(self):
-        raise NotImplementedError("shape type 'cone' is not built yet (SURVEY.md section 8 f-4)")
+        n = self.segments
+        ang = 2.0 * np.pi * np.arange(n, dtype=np.float64) / n
+        ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], axis=1)
+        nxt = np.roll(ring, -1, axis=0)
+        apex = np.tile(np.array([[0.0, 0.0, 1.0]]), (n, 1))
+        centre = np.zeros((n, 3))
+        v0 = np.concatenate([apex, centre])   # lateral (apex, p_i, p_i+1); base (centre, p_i+1, p_i): normal -z
+        v1 = np.concatenate([ring, nxt])
+        v2 = np.concatenate([nxt, ring])
+        T = self.to_world
+        v0, v1, v2 = T.transform_affine(v0), T.transform_affine(v1), T.transform_affine(v2)
+        if (np.linalg.det(T.matrix[:3, :3]) < 0) != self.flip_normals:
+            v1, v2 = v2, v1
+        return _tri_records(v0, v1, v2, _capi.PRIM_TRIANGLE)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -481,9 +504,9 @@ class Scene(Object):
         typ = P["type"][idx]
         p = g[:, 0:3] + u[:, None] * g[:, 3:6] + v[:, None] * g[:, 6:9]
         nrm = g[:, 9:12].copy()
-        sph = typ == _capi.PRIM_SPHERE
+        sph = (typ == _capi.PRIM_SPHERE) & valid   # misses carry t = inf
         if np.any(sph):
-            ps = o + t[:, None] * d
+            ps = o + np.where(sph, t, 0.0)[:, None] * d
             ns = np.where(sph[:, None], ps - g[:, 0:3], 1.0)
             ns = ns / np.maximum(np.linalg.norm(ns, axis=1, keepdims=True), 1e-30)
             p = np.where(sph[:, None], g[:, 0:3] + ns * g[:, 3:4], p)

@@ -17,7 +17,8 @@ def _rays(n, seed, lo, hi):
 
 
 @pytest.mark.parametrize("scene,kw,lo,hi", [("cbox.xml", dict(res=8), -0.95, 0.95), ("simple.xml", dict(res=8, spp=1), -6, 6),
-                                            ("testring.xml", dict(res=8), -0.1, 0.1), ("us_sphere_box.xml", {}, -0.14, 0.14)])
+                                            ("testring.xml", dict(res=8), -0.1, 0.1), ("us_sphere_box.xml", {}, -0.14, 0.14),
+                                            ("us_cone_box.xml", {}, -0.14, 0.14)])
 def test_ray_intersect_and_ray_test(mi, ob, scene, kw, lo, hi):
     sc = mi.load_file(scene_path(scene), **kw)
     n = 20000
@@ -34,6 +35,18 @@ def test_ray_intersect_and_ray_test(mi, ob, scene, kw, lo, hi):
     hit = got["valid"]
     assert np.allclose(np.linalg.norm(got["n"][hit], axis=1), 1, atol=1e-5)
     assert np.allclose(got["p"][hit], o[hit] + got["t"][hit, None] * d[hit], atol=2e-4 * (hi - lo))
+
+
+def test_axis_aligned_rays_through_shared_vertices(mi, ob):
+    """zero direction components and origins in box faces (0 * inf in a slab test): the probe axis meets the centre
+    vertex of the cone's base fan, shared by 96 triangles -- found, and the same primitive as the oracle picks"""
+    sc = mi.load_file(scene_path("us_cone_box.xml"))
+    o = np.array([[0, 0, 0], [0, 0, 0], [0.001, 0, 0], [0, 0, 0.2], [0.15, 0, 0.1]], np.float32)
+    d = np.array([[0, 0, 1], [0, 1, 0], [0, 0, 1], [0, 0, -1], [-1, 0, 0]], np.float32)
+    got = sc.ray_intersect(o, d)
+    t, prim, u, v = ob.OracleScene.from_scene(sc).ray_intersect(o, d, np.full(5, np.inf, np.float32))
+    assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"], t)
+    assert got["valid"].all() and got["t"][0] == pytest.approx(0.06, rel=1e-5)
 
 
 def test_empty_and_single_batches(mi):

@@ -27,7 +27,7 @@ def check(buf, ref):
     assert np.array_equal(buf != 0, ref != 0)
 
 
-@pytest.mark.parametrize("scene,ppr,seed", [("us_plate.xml", 64, 0), ("us_plate.xml", 500, 3), ("us_sphere_box.xml", 200, 1)])
+@pytest.mark.parametrize("scene,ppr,seed", [("us_plate.xml", 64, 0), ("us_plate.xml", 500, 3), ("us_sphere_box.xml", 200, 1), ("us_cone_box.xml", 100, 2)])
 def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed):
     sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed)
     ui = sc.integrator()

@@ -159,6 +159,19 @@ def test_bvh_equals_brute_force(mi, ob, capi):
     for x, y in zip(A, B):
         assert np.array_equal(x, y)
     assert (A[1] != 0xFFFFFFFF).sum() > 100
+    # tessellated cone phantom: the ray up the probe axis meets the cone where the closed form says
+    sc = mi.load_file(scene_path("us_cone_box.xml"))
+    osc = ob.OracleScene.from_scene(sc, capi.ACCEL_BVH)
+    t, prim, *_ = osc.ray_intersect(np.array([[0, 0, 0]], np.float32), np.array([[0, 0, 1]], np.float32), np.array([np.inf], np.float32))
+    M = [s for s in sc.shapes() if s.id() == "cone"][0].to_world.matrix
+    oo, dd = np.linalg.inv(M) @ [0, 0, 0, 1], np.linalg.inv(M) @ [0, 0, 1, 0]            # object space: unit cone
+    cand = [-oo[2] / dd[2]]                                                                # base plane z = 0
+    a = dd[0] ** 2 + dd[1] ** 2 - dd[2] ** 2
+    b = 2 * (oo[0] * dd[0] + oo[1] * dd[1] + (1 - oo[2]) * dd[2])
+    c = oo[0] ** 2 + oo[1] ** 2 - (1 - oo[2]) ** 2
+    cand += list(np.roots([a, b, c]).real)
+    ok = [x for x in cand if x > 0 and -1e-9 <= (oo + x * dd)[2] <= 1 + 1e-9 and np.hypot(*(oo + x * dd)[:2]) <= 1 - (oo + x * dd)[2] + 1e-6]
+    assert prim[0] != 0xFFFFFFFF and t[0] == pytest.approx(min(ok), rel=2e-3)
 
 
 def test_threads_crops_and_sample_ranges_are_consistent(mi, ob):

@@ -211,9 +211,51 @@ def test_transform_composition_order(mi):
     assert np.allclose(la[:3, 0], [-1, 0, 0]) and np.allclose(la[:3, 1], [0, 1, 0]) and np.allclose(la[:3, 2], [0, 0, -1])
 
 
-def test_unknown_plugin_and_cone_are_loud(mi):
+def test_unknown_plugin_is_loud(mi):
     with pytest.raises(KeyError):
         mi.load_dict({"type": "scene", "x": {"type": "no_such_plugin"}})
-    sc = mi.load_dict({"type": "scene", "c": {"type": "cone"}})
-    with pytest.raises(NotImplementedError):
-        sc.flatten()
+    with pytest.raises(ValueError):
+        mi.load_dict({"type": "scene", "c": {"type": "cone", "segments": 2}})
+
+
+def test_cone_definition(mi):
+    """'cone' = closed unit cone (apex (0,0,1), base disc r = 1 at z = 0) under to_world, tessellated."""
+    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "segments": 64}})
+    P = sc.flatten()["prims"]
+    assert len(P) == 128 and np.all(P["type"] == 0)
+    v0, e1, e2, n = (P["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6, 9))
+    assert np.allclose(v0[:64], [0, 0, 1]) and np.allclose(v0[64:], [0, 0, 0])            # lateral fan from the apex, base fan
+    assert np.allclose(np.linalg.norm((v0 + e1)[:, :2], axis=1), 1) and np.allclose((v0 + e1)[:, 2], 0)
+    assert np.allclose(n[64:], [0, 0, -1]) and np.all(n[:64, 2] > 0)                      # outward normals
+    mid = v0[:64] + (e1[:64] + e2[:64]) / 3
+    assert np.all(np.einsum("ij,ij->i", n[:64, :2], mid[:, :2]) > 0)
+    vol = np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6                          # divergence theorem: closed, outward
+    assert vol == pytest.approx(np.pi / 3, rel=2e-3)
+    # the reference's phantom (intent transform, SURVEY App. E): base centre, apex, non-uniform scale
+    sc = mi.load_file(scene_path("us_cone_box.xml"))
+    P = sc.flatten()["prims"]
+    c = P[P["shape"] == [s.id() for s in sc.shapes()].index("cone")]
+    assert len(c) == 192 and len(P) == 197
+    assert np.allclose(c["g"][0, 0:3], [0.0422618, 0.0309976, 0.1451651], atol=1e-6)     # apex = base + axis image
+    assert np.allclose(c["g"][96, 0:3], [0, 0, 0.06], atol=1e-7)
+    v0, e1, e2 = (c["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6))
+    assert np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6 == pytest.approx(np.pi * 0.06 * 0.06 * 0.10 / 3, rel=2e-3)
+    # a mirrored to_world keeps the normals outward
+    m = mi.load_dict({"type": "scene", "c": {"type": "cone", "to_world": mi.ScalarTransform4f().scale([1, -1, 1])}})
+    Q = m.flatten()["prims"]
+    v0, e1, e2 = (Q["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6))
+    assert np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) > 0
+
+
+@needs_ref
+def test_reference_phantoms_all_load(mi):
+    """every MitsubaScenes/*.xml of the reference loads (Mitsuba listed-order transform semantics) and flattens"""
+    import glob
+    files = sorted(glob.glob(os.path.join(REFERENCE, "MitsubaScenes", "*.xml")))
+    assert len(files) == 6
+    for f in files:
+        sc = mi.load_file(f)
+        P = sc.flatten()["prims"]
+        assert len(P) >= 1 and type(sc.integrator()).__name__ == "UltraIntegrator"
+        if "Cone" in f:
+            assert (P["type"] == 0).sum() == 192

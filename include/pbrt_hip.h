@@ -336,6 +336,37 @@ int pbrt_us_put_data(pbrt_ctx *ctx, const pbrt_us_receiver *r, uint32_t n, const
  * shared by pbrt_us_acquire. */
 int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx_delays);
 
+/* ---- image formation behind the hot path ------------------------------------------
+ * The reference hands the channel buffer to the third-party `ultraspy` package (absent here; parity unpinned):
+ * DelayAndSum.beamform(data, GridScan(x, z)) -> compute_envelope -> manual log compression
+ * (USMain.py:126-221).  These entry points are this build's own definition of those three steps. */
+#define PBRT_DAS_NEAREST 0u
+#define PBRT_DAS_LINEAR 1u
+typedef struct pbrt_das_params {
+    uint32_t n_angles, n_elements, time_samples; /* data [n_angles][n_elements][time_samples] (RF, f32) */
+    float fs, sound_speed, t0;                   /* sample s was taken at t0 + s / fs */
+    float f_number;                              /* receive element e used iff |x - x_e| <= z / (2 f_number); 0: all */
+    uint32_t interpolation;                      /* PBRT_DAS_NEAREST / PBRT_DAS_LINEAR */
+    uint32_t compound_mean;                      /* 0: sum over transmissions, 1: mean */
+    uint32_t nx, nz;                             /* GridScan(x, z) */
+} pbrt_das_params;
+
+/* replaces: ultraspy DelayAndSum.beamform(d_data, scan) as called at USMain.py:204.
+ * out[ix][iz] = sum_a sum_e data[a][e](t_tx(a; x, z) + |(x, z) - (elem_x[e], 0)| / c), where the transmit time is the
+ * first arrival of the emitted wavefront, t_tx = min_e' (tx_delays[a][e'] + |(x, z) - (elem_x[e'], 0)| / c)  (equal to
+ * (x sin(theta) + z cos(theta)) / c for the plane-wave delays of pbrt_us_tx_delays inside the aperture's shadow).
+ * Sample positions are evaluated in f64, samples interpolated and summed in f32.  Host pointers. */
+int pbrt_das_beamform(pbrt_ctx *ctx, const pbrt_das_params *p, const float *data, const float *tx_delays,
+                      const float *elem_x, const float *x, const float *z, float *out);
+
+/* replaces: ultraspy DelayAndSum.compute_envelope(d_output, scan) on RF data (USMain.py:205): modulus of the
+ * analytic signal along the axial (z, fastest) axis, i.e. |scipy.signal.hilbert(rf, axis=-1)|.  nz <= 4096. */
+int pbrt_envelope(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const float *rf, float *env);
+
+/* replaces: the manual log compression of USMain.py:210-218: db = 20 log10(env + 1e-12), clipped to
+ * [max(db) - dynamic_range_db, max(db)], mapped to [0, 1].  n values in, n values out. */
+int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic_range_db, float *out);
+
 #ifdef __cplusplus
 }
 #endif

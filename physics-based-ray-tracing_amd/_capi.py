@@ -95,6 +95,15 @@ class UsReceiver(C.Structure):
                 ("time_samples", C.c_uint32)]
 
 
+class DasParams(C.Structure):
+    _fields_ = [("n_angles", C.c_uint32), ("n_elements", C.c_uint32), ("time_samples", C.c_uint32), ("fs", C.c_float),
+                ("sound_speed", C.c_float), ("t0", C.c_float), ("f_number", C.c_float), ("interpolation", C.c_uint32),
+                ("compound_mean", C.c_uint32), ("nx", C.c_uint32), ("nz", C.c_uint32)]
+
+
+DAS_NEAREST, DAS_LINEAR = 0, 1
+
+
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("kernel_ms", C.c_double), ("bounce_ms", C.c_double), ("bounce_launches", C.c_uint32),
@@ -136,6 +145,9 @@ SIGNATURES = {
     "pbrt_us_emitter_sample_ray": (C.c_int, [_P, C.POINTER(UsEmitter), C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F]),
     "pbrt_us_put_data": (C.c_int, [_P, C.POINTER(UsReceiver), C.c_uint32, _F, _F, _F, _F, _F]),
     "pbrt_us_tx_delays": (C.c_int, [C.POINTER(UsParams), _F]),
+    "pbrt_das_beamform": (C.c_int, [_P, C.POINTER(DasParams), _F, _F, _F, _F, _F, _F]),
+    "pbrt_envelope": (C.c_int, [_P, C.c_uint32, C.c_uint32, _F, _F]),
+    "pbrt_log_compress": (C.c_int, [_P, C.c_uint32, _F, C.c_float, _F]),
 }
 
 _lib = None

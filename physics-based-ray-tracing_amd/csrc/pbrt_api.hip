@@ -13,6 +13,7 @@
 
 #include "bvh_build.h"
 #include "kernels_us.h"
+#include "kernels_beamform.h"
 
 static std::string g_ctxless_error;
 
@@ -1053,6 +1054,56 @@ int pbrt_us_put_data(pbrt_ctx *ctx, const pbrt_us_receiver *r, uint32_t n, const
     float *db = S.in(channel_buffer, nb);
     hipLaunchKernelGGL(k_us_put_data, grid, block, 0, st, *r, n, dx, dt, dd, da, db);
     S.back(channel_buffer, db, nb);
+    return S.finish();
+}
+
+// ------------------------------------------------------------------------------------------------
+// image formation behind the hot path: beamform -> envelope -> log compression
+// ------------------------------------------------------------------------------------------------
+int pbrt_das_beamform(pbrt_ctx *ctx, const pbrt_das_params *p, const float *data, const float *tx_delays,
+                      const float *elem_x, const float *x, const float *z, float *out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, p && data && tx_delays && elem_x && x && z && out);
+    NEED(ctx, p->n_angles > 0 && p->n_elements > 0 && p->time_samples > 1 && p->fs > 0.0f && p->sound_speed > 0.0f);
+    NEED(ctx, p->interpolation <= PBRT_DAS_LINEAR && p->f_number >= 0.0f);
+    NEED(ctx, (uint64_t)p->nx * p->nz < 0xffffffffull);
+    const size_t nd = (size_t)p->n_angles * p->n_elements * p->time_samples, ne = (size_t)p->n_angles * p->n_elements;
+    const uint32_t n = p->nx * p->nz;
+    LEAF_BEGIN(ctx, (nd + ne + p->n_elements + p->nx + p->nz + (size_t)n) * 4 + 256);
+    float *dd = S.in(data, nd), *dt = S.in(tx_delays, ne), *de = S.in(elem_x, p->n_elements);
+    float *dx = S.in(x, p->nx), *dz = S.in(z, p->nz);
+    float *dout = S.out<float>(n);
+    hipLaunchKernelGGL(k_das_beamform, grid, block, 0, st, *p, dd, dt, de, dx, dz, dout);
+    S.back(out, dout, n);
+    return S.finish();
+}
+
+int pbrt_envelope(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const float *rf, float *env) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, rf && env && nz <= ENV_MAX_N);
+    const uint32_t n = nx * nz;
+    NEED(ctx, (uint64_t)nx * nz < 0xffffffffull);
+    LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
+    float *din = S.in(rf, n), *dout = S.out<float>(n);
+    const size_t lds = (size_t)nz * 5 * 4;
+    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), block, lds, st, nz, din, dout);
+    (void)grid;
+    S.back(env, dout, n);
+    return S.finish();
+}
+
+int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic_range_db, float *out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, env && out && dynamic_range_db > 0.0f);
+    LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
+    float *din = S.in(env, n), *dout = S.out<float>(n);
+    uint32_t *mx = S.out<uint32_t>(1);
+    HIPCHK(c, hipMemsetAsync(mx, 0, 4, st));
+    hipLaunchKernelGGL(k_env_max, dim3(std::min<uint32_t>(div_up(n, 256), 1024)), block, 0, st, n, din, mx);
+    hipLaunchKernelGGL(k_log_compress, grid, block, 0, st, n, din, mx, dynamic_range_db, dout);
+    S.back(out, dout, n);
     return S.finish();
 }
 

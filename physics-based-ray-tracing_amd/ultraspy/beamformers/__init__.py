@@ -1,0 +1,1 @@
+"""see pbrt_amd.ultraspy"""

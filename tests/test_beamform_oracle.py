@@ -1,0 +1,85 @@
+"""Image formation behind the hot path: the numpy restatement (oracle/beamform.py) against closed
+forms, and the ultraspy-shaped host API.  No GPU."""
+import numpy as np
+import pytest
+
+from oracle import beamform as obf
+
+
+def _point_scatterer_data(xs, zs, angles_deg, E=32, pitch=3e-4, c=1540.0, fs=40e6, T=2400):
+    """one ideal scatterer: element e records a unit impulse (linear-interpolation pair) at the plane-wave transmit
+    time to the scatterer plus the return path"""
+    ex = (pitch * (np.arange(E, dtype=np.float32) - (E - 1) / 2)).astype(np.float32)
+    th = np.deg2rad(np.asarray(angles_deg, dtype=np.float64))
+    tx = (ex[None, :].astype(np.float64) * np.sin(th)[:, None] / c).astype(np.float32)      # CustomIntegrator.py:254-257
+    data = np.zeros((len(th), E, T), np.float32)
+    dist = np.sqrt((xs - ex.astype(np.float64)) ** 2 + zs ** 2)
+    for a in range(len(th)):
+        t_tx = np.min(tx[a].astype(np.float64) + dist / c)
+        s = (t_tx + dist / c) * fs
+        i0 = np.floor(s).astype(int)
+        w = s - i0
+        data[a, np.arange(E), i0] += (1 - w).astype(np.float32)
+        data[a, np.arange(E), i0 + 1] += w.astype(np.float32)
+    return data, tx, ex, c, fs
+
+
+def test_point_scatterer_focuses_where_it_is():
+    xs, zs = 0.0012, 0.0205
+    data, tx, ex, c, fs = _point_scatterer_data(xs, zs, [-10, 0, 10])
+    x = np.arange(-0.004, 0.004001, 1e-4)
+    z = np.arange(0.015, 0.026, 1e-4)
+    img = obf.das_beamform(data, tx, ex, x, z, fs, c, f_number=0.0)
+    ix, iz = np.unravel_index(np.argmax(img), img.shape)
+    assert abs(x[ix] - xs) <= 1e-4 and abs(z[iz] - zs) <= 1e-4
+    # at the scatterer every (angle, element) trace contributes ~1: coherent sum ~ A * E
+    assert img[ix, iz] > 0.55 * data.shape[0] * data.shape[1]          # two-sample impulses read through a linear interpolator
+    # plane-wave delays: first arrival == (x sin + z cos) / c under the aperture
+    th = np.deg2rad(10.0)
+    d = np.sqrt((xs - ex.astype(np.float64)) ** 2 + zs ** 2)
+    assert np.min(tx[2] + d / c) == pytest.approx((xs * np.sin(th) + zs * np.cos(th)) / c, rel=2e-4)
+    # f-number 1 drops the elements farther than z / 2 from the pixel column; nearest vs linear agree at the peak
+    img_f = obf.das_beamform(data, tx, ex, x, z, fs, c, f_number=1.0)
+    n_used = np.sum(np.abs(x[ix] - ex) <= z[iz] / 2)
+    assert img_f[ix, iz] <= img[ix, iz] and img_f[ix, iz] > 0.55 * 3 * n_used
+    img_n = obf.das_beamform(data, tx, ex, x, z, fs, c, f_number=0.0, interpolation="nearest")
+    assert np.unravel_index(np.argmax(img_n), img_n.shape) == (ix, iz)
+    assert np.allclose(obf.das_beamform(data, tx, ex, x, z, fs, c, f_number=0.0, compound="mean"), img / 3)
+
+
+def test_envelope_is_the_analytic_signal_modulus():
+    sp = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(0)
+    for N in (64, 127, 398):
+        x = rng.normal(size=(5, N))
+        assert np.allclose(obf.envelope(x), np.abs(sp.hilbert(x, axis=-1)), rtol=1e-12, atol=1e-12)
+    n = np.arange(256)
+    tone = 0.7 * np.cos(2 * np.pi * 16 * n / 256 + 0.3)          # integer number of cycles: envelope == amplitude
+    assert np.allclose(obf.envelope(tone[None])[0], 0.7, atol=1e-12)
+
+
+def test_log_compression_values():
+    env = np.array([1.0, 0.1, 1e-3, 1e-6, 0.0])
+    out = obf.log_compress(env, 60.0)                             # 0, -20, -60, -120 (clipped), -240 (clipped) dB
+    assert np.allclose(out, [1.0, 40 / 60, 0.0, 0.0, 0.0], atol=1e-9)
+    assert np.allclose(obf.log_compress(env * 7.5, 60.0), out, atol=1e-9)   # scale free
+
+
+def test_ultraspy_shaped_front_end(mi):
+    from pbrt_amd.ultraspy.beamformers.das import DelayAndSum
+    from pbrt_amd.ultraspy.probes.factory import build_probe
+    from pbrt_amd.ultraspy.scan import GridScan
+    assert DelayAndSum is mi.DelayAndSum and GridScan is mi.GridScan and build_probe is mi.build_probe
+    probe = build_probe(geometry_type="linear", nb_elements=64, pitch=1.2e-4, central_freq=3e6, bandwidth=70)   # USMain.py:130-136
+    ui = mi.load_file(__import__("conftest").scene_path("us_plate.xml")).integrator()
+    assert np.array_equal(probe.geometry[0], np.asarray(ui.elem_x, dtype=np.float32))
+    scan = GridScan(np.arange(-0.01, 0.01, 1e-3), np.arange(0.001, 0.02, 1e-3))
+    assert scan.shape == (20, 19)
+    bf = DelayAndSum(on_gpu=False)
+    with pytest.raises(RuntimeError):
+        bf.beamform(np.zeros((1, 2, 64, 10), np.float32), scan)
+    with pytest.raises(NotImplementedError):
+        build_probe(geometry_type="convex", nb_elements=64, pitch=1e-4, central_freq=3e6)
+    with pytest.raises(KeyError):
+        bf.update_setup("no_such_option", 1)
+    assert "DelayAndSum" in str(bf)

@@ -1,0 +1,127 @@
+"""HIP image formation (pbrt_das_beamform / pbrt_envelope / pbrt_log_compress, through the C-ABI) against the numpy
+restatement, the end-to-end B-mode of the reference's us_render, and its finite-difference roughness loop
+(USMain.py:93-224, :257-289).  SURVEY section 8 f-1 / f-2."""
+import numpy as np
+import pytest
+
+from conftest import scene_path
+from oracle import beamform as obf
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_case(seed, A, E, T, c=1500.0, fs=20e6, pitch=3e-4):
+    rng = np.random.default_rng(seed)
+    data = rng.normal(size=(A, E, T)).astype(np.float32)
+    ex = (pitch * (np.arange(E, dtype=np.float32) - (E - 1) / 2)).astype(np.float32)
+    th = np.deg2rad(np.linspace(-12, 12, A))
+    tx = (ex[None, :].astype(np.float64) * np.sin(th)[:, None] / c).astype(np.float32)
+    return data, tx, ex, c, fs
+
+
+@pytest.mark.parametrize("interp,fnum,compound", [("linear", 1.0, "sum"), ("linear", 0.0, "mean"), ("nearest", 1.5, "sum")])
+def test_das_matches_the_restatement(mi, interp, fnum, compound):
+    data, tx, ex, c, fs = _rand_case(1, 3, 16, 700)
+    x = np.linspace(-0.004, 0.004, 37)
+    z = np.linspace(0.0005, 0.024, 53)          # the deepest rows run off the end of the traces: zero contribution
+    got = mi.das_beamform(data, tx, ex, x, z, fs, c, f_number=fnum, interpolation=interp, compound=compound)
+    ref = obf.das_beamform(data, tx, ex, x, z, fs, c, f_number=fnum, interpolation=interp, compound=compound)
+    assert got.shape == (37, 53) and got.dtype == np.float32
+    if interp == "nearest":    # a sample position within 1e-9 of a half-integer may round either way: allow a handful
+        bad = np.abs(got - ref) > 1e-4 * np.abs(ref).max()
+        assert bad.mean() < 2e-3
+    else:
+        assert np.allclose(got, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+    assert np.abs(ref).max() > 1.0
+
+
+def test_das_edges(mi):
+    data, tx, ex, c, fs = _rand_case(2, 1, 4, 64)
+    one = mi.das_beamform(data, tx, ex, [0.0], [0.001], fs, c, f_number=0.0)              # 1 x 1 grid
+    assert one.shape == (1, 1) and one[0, 0] == pytest.approx(obf.das_beamform(data, tx, ex, [0.0], [0.001], fs, c, f_number=0.0)[0, 0], abs=1e-5)
+    far = mi.das_beamform(data, tx, ex, [0.0, 0.001], [1.0, 2.0], fs, c)                  # beyond the recorded time: zeros
+    assert np.array_equal(far, np.zeros((2, 2), np.float32))
+    with pytest.raises(RuntimeError):
+        mi.das_beamform(data, tx, ex, [0.0], [0.001], -1.0, c)                             # fs <= 0: error code, not a crash
+    with pytest.raises(ValueError):
+        mi.das_beamform(data[0], tx, ex, [0.0], [0.001], fs, c)
+
+
+@pytest.mark.parametrize("N", [2, 64, 127, 398, 1024])
+def test_envelope_matches_the_restatement(mi, N):
+    rng = np.random.default_rng(N)
+    rf = rng.normal(size=(7, N)).astype(np.float32)
+    got = mi.envelope(rf)
+    ref = obf.envelope(rf)
+    assert got.shape == rf.shape and np.allclose(got, ref, rtol=0, atol=1e-4 * ref.max())
+    n = np.arange(N)
+    if N >= 64:
+        tone = (0.5 * np.cos(2 * np.pi * 8 * n / N)).astype(np.float32)
+        assert np.allclose(mi.envelope(tone[None])[0], 0.5, atol=2e-5)
+    with pytest.raises(RuntimeError):
+        mi.envelope(np.zeros((1, 5000), np.float32))                                       # nz > 4096
+
+
+def test_log_compress_matches_the_restatement(mi):
+    rng = np.random.default_rng(3)
+    env = np.abs(rng.normal(size=(40, 50))).astype(np.float32) ** 4
+    env[0, 0] = 0.0
+    got = mi.log_compress(env, 60.0)
+    assert got.shape == env.shape and np.allclose(got, obf.log_compress(env, 60.0), atol=2e-6)
+    assert got.min() == 0.0 and got.max() == 1.0
+    assert np.allclose(mi.log_compress(env, 40.0), obf.log_compress(env, 40.0), atol=2e-6)
+
+
+def test_full_size_linearity(mi):
+    """BASELINE-size input (5 x 64 x 10000 channel buffer, lambda / 4 grid of USMain.py:180-194): DAS is linear in the data"""
+    data1, tx, ex, c, fs = _rand_case(5, 5, 64, 10000, c=1480.0, fs=50e6, pitch=1.2e-4)
+    data2 = _rand_case(6, 5, 64, 10000)[0]
+    lam = 1480.0 / 3e6
+    x = np.arange(-0.04, 0.04 + lam / 4, lam / 4)
+    z = np.arange(0.001, 0.05 + lam / 4, lam / 4)
+    a = mi.das_beamform(data1, tx, ex, x, z, fs, c)
+    b = mi.das_beamform(data2, tx, ex, x, z, fs, c)
+    ab = mi.das_beamform(2.0 * data1 - 3.0 * data2, tx, ex, x, z, fs, c)
+    assert a.shape == (len(x), len(z)) and np.abs(a).max() > 1
+    assert np.allclose(ab, 2.0 * a - 3.0 * b, atol=2e-4 * np.abs(ab).max())
+    env = mi.envelope(a)
+    assert np.all(env >= np.abs(a) - 1e-3 * env.max())                                      # |analytic signal| >= |signal|
+    band = slice(37, 41)                                                                    # a few columns against the restatement
+    assert np.allclose(a[band], obf.das_beamform(data1, tx, ex, x[band], z, fs, c), atol=2e-5 * np.abs(a).max())
+
+
+def test_bmode_of_the_plate_and_fd_roughness_loop(mi):
+    """us_render end to end on the USMain.py scene, then the reference's finite-difference loop (:257-289) with
+    common random numbers (same seed for every forward run -- the reference is unseeded and its FD gradient is noise)"""
+    sc = mi.load_file(scene_path("us_plate.xml"))
+    kw = dict(x_range=(-0.01, 0.01), z_range=(0.03, 0.07), seed=11, paths_per_ray=256)
+    display, bmode, (xs, zs) = mi.us_render(sc, **kw)
+    assert display.shape == (len(zs), len(xs)) and bmode.shape == (len(xs), len(zs))
+    assert display.min() >= 0.0 and display.max() == 1.0 and np.isfinite(bmode).all()
+    # the plate crosses the probe axis at z = 0.05 (45 degree tilt): the brightest pixel of the centre column is there
+    col = bmode[len(xs) // 2]
+    assert abs(zs[np.argmax(col)] - 0.05) < 0.004
+    params = mi.traverse(sc)
+    key = [k for k in params.keys() if k.endswith("flat_plate.bsdf.roughness")][0]
+
+    def forward(rough):                                                                     # USMain.py:262-269
+        params[key] = rough
+        params.update()
+        return mi.us_render(sc, **kw)[1]
+
+    target = forward(0.7)
+    again = forward(0.7)
+    loss = lambda b: float(np.mean((b.astype(np.float64) - target) ** 2))                   # :273-274
+    scale = float(np.mean(target.astype(np.float64) ** 2))
+    assert loss(again) < 1e-8 * scale                                                       # reproducible up to the order of the atomics
+    l3, l5 = loss(forward(0.3)), loss(forward(0.5))
+    assert l3 > 1e-6 * scale and l5 > 1e-6 * scale and np.isfinite([l3, l5]).all()         # other roughness: another image
+    rough, hist = 0.4, []
+    for it in range(3):                                                                     # :279-289, step size normalised
+        f0, f1 = loss(forward(rough)), loss(forward(rough + 1e-2))
+        grad = (f1 - f0) / 1e-2
+        g2 = (loss(forward(rough + 1e-2)) - loss(forward(rough))) / 1e-2                    # common random numbers: the
+        assert np.isfinite(grad) and abs(grad - g2) <= 1e-5 * abs(grad) + 1e-12 * scale     # FD gradient is reproducible
+        hist.append((rough, f0, grad))
+        rough = float(np.clip(rough - 0.05 * np.sign(grad), 1e-4, 1.0))
+    assert len(hist) == 3 and all(np.isfinite(h).all() for h in hist)

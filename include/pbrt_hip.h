@@ -146,6 +146,8 @@ typedef struct pbrt_film_desc {
 
 #define PBRT_FILM_RAW_ACCUM 1u /* output 4 floats/pixel (sum w*rgb, sum w) un-normalised: \
                                   for sample-sharded multi-GPU reduction */
+#define PBRT_FILM_NO_REPACK 2u /* diagnostic: BVH scenes, do not re-densify the live paths before bounces >= 2 \
+                                  (same image either way) */
 
 /* ---- ultrasound (acoustic) mode ----------------------------------------------------------- */
 /* Parameter block of UltraIntegrator (CustomIntegrator.py:13-48) plus the sensor transform

@@ -55,6 +55,22 @@ __host__ __device__ constexpr uint32_t seg_threads(int accel) {
 __host__ __device__ constexpr uint32_t seg_waves_per_eu(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH / 256 : SEG_WAVES_PER_EU;
 }
+// BVH kernels compact per WAVE: every wave owns REGION / (SEG / 64) slots of its workgroup's region, walks its own
+// live prefix 64 paths at a time and packs its survivors with ballot + mbcnt alone -- no barrier after the scene is
+// staged.  Traversal time varies a lot from wave to wave (measured: 2.7 of 4 possible waves per SIMD active with the
+// per-chunk workgroup barrier), so the 16 waves of a workgroup must not wait for each other.  (The brute-force
+// kernels keep the workgroup scan: there the barrier is cheap and private regions cost registers, DESIGN.md.)
+__host__ __device__ constexpr bool rad_wave_private(int accel) {
+#ifdef PBRT_BVH_WG_COMPACT  // diagnostic builds only (A/B against the workgroup-level scan)
+    return false && accel;
+#else
+    return accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS;
+#endif
+}
+// live-path counters / statistics rows per region (one per workgroup, or one per wave)
+__host__ __device__ constexpr uint32_t rad_owners_per_region(int accel) {
+    return rad_wave_private(accel) ? seg_threads(accel) / 64 : 1;
+}
 #define TAB_MAX 32
 #define TAB_DW (TAB_MAX * 16 + TAB_MAX * 8 + TAB_MAX * 12 + TAB_MAX + TAB_MAX)
 
@@ -198,14 +214,31 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const uint32_t seg = blockIdx.x;  // region index
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REGION = rad_region_segs(ACCEL) * SEG;
-    const uint32_t base = seg * REGION;
+    constexpr bool WP = rad_wave_private(ACCEL);       // per-wave compaction (BVH kernels)
+    constexpr uint32_t W = SEG / 64, WREG = REGION / W;  // waves per workgroup, slots owned by one wave
+    constexpr uint32_t CH = WP ? 64u : SEG;            // paths per chunk of the walk
+    const uint32_t lane_c = WP ? (tid & 63u) : tid;    // position inside the chunk
+    const uint32_t own = WP ? seg * W + (tid >> 6) : seg;  // live counter / statistics row of this wave / workgroup
+    const uint32_t base = WP ? seg * REGION + (tid >> 6) * WREG : seg * REGION;
     uint32_t cnt_in;
     if (FIRST) {
-        cnt_in = a.n_paths > base ? min(a.n_paths - base, REGION) : 0u;
+        cnt_in = a.n_paths > base ? min(a.n_paths - base, WP ? WREG : REGION) : 0u;
     } else {
-        cnt_in = a.seg_in[seg];
+        cnt_in = a.seg_in[own];
     }
-    if (cnt_in == 0) {  // uniform across the workgroup
+    if (WP) {
+        // the workgroup stages the scene together: leave only if no wave of it has work (same answer in every wave)
+        cnt_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_in);
+        uint32_t c = 0;
+        if ((tid & 63u) < W) {
+            const uint32_t b2 = seg * REGION + (tid & 63u) * WREG;
+            c = FIRST ? (a.n_paths > b2 ? 1u : 0u) : a.seg_in[seg * W + (tid & 63u)];
+        }
+        if (__ballot(c != 0) == 0) {
+            if ((tid & 63u) == 0) a.seg_out[own] = 0;
+            return;
+        }
+    } else if (cnt_in == 0) {  // uniform across the workgroup
         if (tid == 0) a.seg_out[seg] = 0;
         return;
     }
@@ -244,10 +277,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     uint32_t out_off = 0;      // survivors written so far (front of this region of the `out` state)
     uint32_t ns_acc = 0, nh_acc = 0;
     // the region's live paths sit compacted at its front: walk them SEG at a time; dead slots cost nothing
-    for (uint32_t it0 = 0; it0 < (REGION > SEG ? cnt_in : 1u); it0 += SEG) {  // single trip when REGION == SEG
+    for (uint32_t it0 = 0; it0 < (REGION > SEG ? cnt_in : 1u); it0 += CH) {  // single trip when REGION == SEG
     const uint32_t buf = (it0 / SEG) & 1u;
-    const bool alive = it0 + tid < cnt_in;
-    const uint32_t slot = base + it0 + tid;
+    const bool alive = it0 + lane_c < cnt_in;
+    const uint32_t slot = base + it0 + lane_c;
     bool survive = false;
     bool did_seg = false, did_shadow = false;
     V3 o, d, thr, L;
@@ -378,6 +411,12 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const unsigned long long bal = __ballot(survive);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
     const unsigned long long bseg = __ballot(did_seg), bshd = __ballot(did_shadow);
+    uint32_t off = 0, total = 0;
+    if (WP) {  // the wave packs its own survivors behind its own cursor: no LDS, no barrier
+        total = (uint32_t)__popcll(bal);
+        ns_acc += (uint32_t)__popcll(bseg);
+        nh_acc += (uint32_t)__popcll(bshd);
+    } else {
     if ((tid & 63) == 0) {
         wave_tot[buf][wid] = (uint32_t)__popcll(bal);
         wave_seg[buf][wid] = (uint32_t)__popcll(bseg);
@@ -386,8 +425,6 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     __syncthreads();
     // exclusive scan over the waves' survivor counts on the scalar unit: one LDS read per lane, then
     // v_readlane + s_add per wave (the per-lane form cost 40 VALU per wave-bounce)
-    uint32_t off = 0, total = 0;
-    {
         const uint32_t t_lane = wave_tot[buf][tid & (SEG / 64 - 1)];
         const uint32_t wid_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wid);
 #pragma unroll
@@ -417,19 +454,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         bst(r_out, v4 + 14 * row, 0, __uint_as_float(home));
     }
     out_off += total;
-    if (tid == 0) {
+    if (!WP && tid == 0) {
         for (uint32_t w = 0; w < SEG / 64; ++w) {
             ns_acc += wave_seg[buf][w];
             nh_acc += wave_shd[buf][w];
         }
     }
     }  // chunk loop
-    if (tid == 0) {
-        a.seg_out[seg] = out_off;
+    if (WP ? (tid & 63u) == 0 : tid == 0) {
+        a.seg_out[own] = out_off;
         // per-region statistics rows (plain read-modify-write by the owning workgroup; launches of a
         // call are ordered on the stream).  NOT global atomics: 3 same-line atomics per workgroup
         // serialise at ~12 ns each and were the whole kernel time (DESIGN.md "What did not work").
-        unsigned long long *row = a.stats + seg;
+        unsigned long long *row = a.stats + own;
         const size_t stride = a.stat_stride;
         row[0] += ns_acc;
         row[stride] += nh_acc;
@@ -621,10 +658,11 @@ __global__ __launch_bounds__(256) void k_film_resolve(const float *acc, float *o
 }
 
 // upload of caller rays for Integrator.sample(): o,d [3][n] SoA + tmax -> state slots
-__global__ __launch_bounds__(256) void k_init_rays(float *st, uint32_t *seg_cnt, uint32_t cap, uint32_t region, uint32_t n,
+// region: slots per live counter (a region, or the part of it one wave owns); n_cnt counters
+__global__ __launch_bounds__(256) void k_init_rays(float *st, uint32_t *seg_cnt, uint32_t n_cnt, uint32_t region, uint32_t n,
                                                    const float *o, const float *d, const float *tmax) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (cap / region)) seg_cnt[i] = n > i * region ? min(n - i * region, region) : 0u;
+    if (i < n_cnt) seg_cnt[i] = n > i * region ? min(n - i * region, region) : 0u;
     if (i >= n) return;
     float *s = st + (state_voff(i) >> 2);  // tiled SoA: row k at +64 * k floats
     s[0 * 64] = o[i];
@@ -642,4 +680,61 @@ __global__ __launch_bounds__(256) void k_init_rays(float *st, uint32_t *seg_cnt,
     s[12 * 64] = tmax[i];  // consumed as tmax by the first bounce
     s[13 * 64] = -1.0f;
     s[14 * 64] = __uint_as_float(i);
+}
+
+// ---- repack (BVH kernels, depth >= 2): deal the live paths evenly to as few workgroups as fill the GPU ----------
+// Per-wave compaction keeps every path inside the 512 slots its wave owns.  When few paths are left (open scenes:
+// 22 % after two bounces of the ring scene, 1 % after five) every workgroup still stages the whole scene in LDS for
+// a handful of paths and runs with mostly empty waves: 330-1500 ps per path instead of 160.  k_scan_owners turns the
+// owners' live counts into exclusive offsets (one workgroup; <= a few 10^4 counts) and picks the new shape: the
+// paths go to G = clamp(ceil(total / REGION), min_wg, n_regions) workgroups (min_wg = one per CU: fewer would leave
+// CUs idle, more would stage the scene more often), `quota` paths per wave.  k_repack_copy moves path j of owner i
+// to its new slot in the spare state buffer (120 B per live path, a fraction of a BVH bounce).  Slot order changes,
+// results do not (the film gathers by `home`).
+__global__ __launch_bounds__(1024) void k_scan_owners(const uint32_t *cnt, uint32_t n_own, uint32_t wreg, uint32_t owners_per_wg,
+                                                     uint32_t min_wg, uint32_t *offs, uint32_t *cnt_new, uint32_t *quota_out) {
+    __shared__ uint32_t part[1024];
+    const uint32_t t = threadIdx.x, per = (n_own + 1023u) / 1024u;
+    const uint32_t lo = min(t * per, n_own), hi = min(lo + per, n_own);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += cnt[i];
+    part[t] = s;
+    __syncthreads();
+    for (uint32_t w = 1; w < 1024; w <<= 1) {  // Hillis-Steele inclusive scan
+        const uint32_t v = t >= w ? part[t - w] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t total = part[1023];
+    uint32_t run = part[t] - s;  // exclusive prefix of this thread's block of owners
+    for (uint32_t i = lo; i < hi; ++i) {
+        offs[i] = run;
+        run += cnt[i];
+    }
+    const uint32_t n_wg = n_own / owners_per_wg, region = wreg * owners_per_wg;
+    const uint32_t g = min(max((total + region - 1u) / region, min(min_wg, n_wg)), n_wg);
+    const uint32_t act = g * owners_per_wg;                       // owners that receive paths
+    const uint32_t quota = max((total + act - 1u) / act, 1u);     // <= wreg because g * region >= total
+    if (t == 0) *quota_out = quota;
+    for (uint32_t i = lo; i < hi; ++i) cnt_new[i] = total > i * quota ? min(total - i * quota, quota) : 0u;
+}
+
+// one wave per source owner
+__global__ __launch_bounds__(256) void k_repack_copy(const float *__restrict__ in, float *__restrict__ out,
+                                                     const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ offs,
+                                                     const uint32_t *__restrict__ quota_p, uint32_t n_own, uint32_t wreg) {
+    const uint32_t own = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (own >= n_own) return;
+    const uint32_t n = cnt[own], dense0 = offs[own], src0 = own * wreg, quota = *quota_p;
+    for (uint32_t j = lane; j < n; j += 64u) {
+        const uint32_t dense = dense0 + j, o2 = dense / quota, p2 = dense - o2 * quota;
+        const float *s = in + (state_voff(src0 + j) >> 2);
+        float *d = out + (state_voff(o2 * wreg + p2) >> 2);
+        float v[N_STATE];
+#pragma unroll
+        for (int k = 0; k < N_STATE; ++k) v[k] = s[k * 64];
+#pragma unroll
+        for (int k = 0; k < N_STATE; ++k) d[k * 64] = v[k];
+    }
 }

@@ -24,6 +24,7 @@ struct DevBuf {
 
 struct pbrt_ctx {
     int device = 0;
+    int n_cu = 256;  // compute units (MI355X: 256); read from the device properties
     hipStream_t stream = nullptr;
     std::string err;
     pbrt_stats stats{};
@@ -181,7 +182,10 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
         return PBRT_E_DEVICE;
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->lds_limit = (uint32_t)prop.sharedMemPerBlock;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->lds_limit = (uint32_t)prop.sharedMemPerBlock;
+        if (prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     *out = c;
     return PBRT_OK;
 }
@@ -400,14 +404,23 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
-    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
-    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    // BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
+    const bool repack = rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
+    float *stC = repack ? (float *)c->buf("stateC", (size_t)cap * N_STATE * 4) : nullptr;
+    // live counters and statistics rows: one per region, or one per wave of it (BVH kernels: wave-private compaction)
+    const uint32_t n_own = nseg * rad_owners_per_region(s->accel_kernel);
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
+    uint32_t *segC = repack ? (uint32_t *)c->buf("segC", (size_t)n_own * 4) : nullptr;
+    uint32_t *offs = repack ? (uint32_t *)c->buf("seg_offs", (size_t)n_own * 4) : nullptr;
+    uint32_t *quota = repack ? (uint32_t *)c->buf("seg_quota", 64) : nullptr;
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
+    if (repack && (!stC || !segC || !offs || !quota)) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemsetAsync(acc, 0, film_px * 16, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
@@ -423,7 +436,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.cam = *cam;
         a.Lhome = Lhome;
         a.stats = segstats;
-    a.stat_stride = nseg;
+        a.stat_stride = n_own;
         a.cap = cap;
         a.n_paths = (uint32_t)(npix_r * sc);
         a.max_depth = f->max_depth;
@@ -452,6 +465,14 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             a.out = out;
             a.seg_in = sin;
             a.seg_out = sout;
+            if (repack && depth >= 2) {
+                const uint32_t owners = rad_owners_per_region(s->accel_kernel), wreg = REGION / owners;
+                hipLaunchKernelGGL(k_scan_owners, dim3(1), dim3(1024), 0, st, sin, n_own, wreg, owners, (uint32_t)c->n_cu, offs, segC,
+                                   quota);
+                hipLaunchKernelGGL(k_repack_copy, dim3(div_up(n_own, 4)), dim3(256), 0, st, in, stC, sin, offs, quota, n_own, wreg);
+                a.in = stC;
+                a.seg_in = segC;
+            }
             // ONE event pair per pass around its bounce launches (a pair per launch costs ~8 us of queue bubbles each)
             if (depth == 0) {
                 pass_e1 = c->event(n_ev + 1);
@@ -470,8 +491,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             std::swap(sin, sout);
             // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces
             if (f->max_depth > 32 && (depth & 7) == 7) {
-                std::vector<uint32_t> cnt(nseg_pass);
-                HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nseg_pass * 4, hipMemcpyDeviceToHost, st));
+                std::vector<uint32_t> cnt(n_own);
+                HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)n_own * 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
                 uint64_t live = 0;
                 for (uint32_t v : cnt) live += v;
@@ -510,7 +531,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, nseg, (size_t)nseg, dstats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -575,10 +596,11 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
-    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
-    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    const uint32_t owners = rad_owners_per_region(s->accel_kernel), n_own = nseg * owners;  // see render_impl
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
@@ -590,13 +612,13 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
     HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
     HIPCHK(c, hipMemsetAsync(Lhome, 0, (size_t)cap * 16, st));
-    hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, stA, segA, cap, REGION, n, io,
+    hipLaunchKernelGGL(k_init_rays, dim3(div_up(std::max(n, n_own), 256)), dim3(256), 0, st, stA, segA, n_own, REGION / owners, n, io,
                        io + 3 * (size_t)n, io + 6 * (size_t)n);
     RadArgs a{};
     a.sc = s->ds;
     a.Lhome = Lhome;
     a.stats = segstats;
-    a.stat_stride = nseg;
+    a.stat_stride = n_own;
     a.cap = cap;
     a.n_paths = n;
     a.max_depth = max_depth;
@@ -622,8 +644,8 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         std::swap(in, out);
         std::swap(sin, sout);
         if (max_depth > 32 && (depth & 7) == 7) {
-            std::vector<uint32_t> cnt(nseg);
-            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nseg * 4, hipMemcpyDeviceToHost, st));
+            std::vector<uint32_t> cnt(n_own);
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)n_own * 4, hipMemcpyDeviceToHost, st));
             HIPCHK(c, hipStreamSynchronize(st));
             uint64_t live = 0;
             for (uint32_t v : cnt) live += v;

@@ -185,6 +185,8 @@ typedef struct pbrt_us_params {
 #define PBRT_USQ_NEVER_ENTER 0x20u  /* A4: 'entering' is always false                          */
 #define PBRT_USQ_CLAMP_TIME 0x40u   /* B3 (Dr.Jit variant): clamp t_idx instead of dropping    */
 #define PBRT_USQ_NO_TOF_ACCUM 0x80u /* B2 (Dr.Jit variant): tof never accumulates              */
+#define PBRT_USQ_NO_CARRIER 0x100u  /* f-3 pulse model: deposit atten*amp*w_i*w_o without the sin(phase) factor of :348; the carrier
+                                       comes from pbrt_us_apply_pulse (not a reference quirk)  */
 #define PBRT_USQ_REFERENCE                                                                  \
     (PBRT_USQ_DIAG_SAMPLE | PBRT_USQ_REF_REFLECT | PBRT_USQ_UNIT_GGX_PDF | PBRT_USQ_DOUBLE_LOCAL | \
      PBRT_USQ_MIXED_FRAMES | PBRT_USQ_NEVER_ENTER)
@@ -368,6 +370,16 @@ int pbrt_envelope(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const float *rf, floa
 /* replaces: the manual log compression of USMain.py:210-218: db = 20 log10(env + 1e-12), clipped to
  * [max(db) - dynamic_range_db, max(db)], mapped to [0, 1].  n values in, n values out. */
 int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic_range_db, float *out);
+
+/* SURVEY.md section 8 f-3, the pulse model of the reference's prototype (RayTracingV0.py:194-204, "UltraRay Eq. 14"):
+ *   pulse(t; t0, amp) = amp * sin(2 pi fc (t - t0)) * exp(-(t - t0)^2 / sigma^2).
+ * With echoes deposited as plain amplitudes on the sample grid (PBRT_USQ_NO_CARRIER) the RF trace is the discrete
+ * convolution of every trace with h[k] = sin(2 pi fc k / fs) * exp(-(k / fs)^2 / sigma^2), |k| <= ceil(2.5 sigma fs):
+ * out[tr][n] = sum_k in[tr][n - k] * h[k]  (zero outside the trace).  n_traces x time_samples values, host pointers;
+ * in and out must not overlap.  [DEFINE] sigma = wave_cycles / (4 fc) turns the integrator's unused `wave_cycles`
+ * (CustomIntegrator.py:20) into the pulse length. */
+int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
+                        const float *in, float *out);
 
 #ifdef __cplusplus
 }

@@ -72,3 +72,20 @@ def log_compress(env, dynamic_range=60.0):
     mx = db.max()
     mn = mx - dynamic_range
     return (np.clip(db, mn, mx) - mn) / dynamic_range
+
+
+def pulse_taps(fs, frequency, sigma):
+    """h[k] = sin(2 pi fc k / fs) exp(-(k / fs)^2 / sigma^2), |k| <= ceil(2.5 sigma fs)   (RayTracingV0.py:194-198)"""
+    fs, fc, sg = float(np.float32(fs)), float(np.float32(frequency)), float(np.float32(sigma))
+    K = int(np.ceil(2.5 * sg * fs))
+    t = np.arange(-K, K + 1) / fs
+    return np.sin(2 * np.pi * fc * t) * np.exp(-(t * t) / (sg * sg)), K
+
+
+def apply_pulse(traces, fs, frequency, sigma):
+    """every trace (last axis) convolved with the pulse: out[n] = sum_k in[n - k] h[k], zero outside (pbrt_us_apply_pulse)"""
+    x = np.asarray(traces, dtype=np.float64)
+    h, K = pulse_taps(fs, frequency, sigma)
+    flat = x.reshape(-1, x.shape[-1])
+    out = np.stack([np.convolve(r, h, mode="full")[K:K + x.shape[-1]] for r in flat])
+    return out.reshape(x.shape)

@@ -1039,7 +1039,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                            // :341
                     float w_o = dot(d, si.n) / num_rays;                                       // :286-287,345
                     float fd = directivity_weight_i(sec_dir, tn, am, ac) * w_o;                // :345
-                    float pressure = atten * amp * fd * sinf(phase);                           // :348
+                    float pressure = atten * amp * fd * ((p->quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase));  // :348 / f-3
                     float tf = rintf(total_time * p->fs);                                      // :351-352 (half-to-even)
                     if (p->quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
                     if (tf >= 0.0f && tf < (float)T && visible)                                // :353

@@ -27,7 +27,8 @@ from .scene import (Film, Object, ParamFlags, ReconstructionFilter, Sampler, Sce
                     load_file, register_bsdf, register_emitter, register_film, register_integrator, register_rfilter,
                     register_sampler, register_sensor, register_shape, traverse)
 from .transforms import Properties, ScalarTransform4f, Transform4f
-from .beamform import DelayAndSum, GridScan, build_probe, das_beamform, envelope, log_compress, us_render
+from .beamform import (DelayAndSum, GridScan, apply_pulse, build_probe, das_beamform, envelope, log_compress,
+                       us_render)
 
 # NB: the receive-side accumulator class `CustomSensor` is reached as pbrt_amd.CustomSensor.CustomSensor (module of
 # the same name, like the reference's CustomSensor.py) or pbrt_amd.plugins.CustomSensor.

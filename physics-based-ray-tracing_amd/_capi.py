@@ -33,6 +33,7 @@ USQ_MIXED_FRAMES = 0x10
 USQ_NEVER_ENTER = 0x20
 USQ_CLAMP_TIME = 0x40
 USQ_NO_TOF_ACCUM = 0x80
+USQ_NO_CARRIER = 0x100
 USQ_REFERENCE = (USQ_DIAG_SAMPLE | USQ_REF_REFLECT | USQ_UNIT_GGX_PDF | USQ_DOUBLE_LOCAL
                  | USQ_MIXED_FRAMES | USQ_NEVER_ENTER)
 
@@ -148,6 +149,7 @@ SIGNATURES = {
     "pbrt_das_beamform": (C.c_int, [_P, C.POINTER(DasParams), _F, _F, _F, _F, _F, _F]),
     "pbrt_envelope": (C.c_int, [_P, C.c_uint32, C.c_uint32, _F, _F]),
     "pbrt_log_compress": (C.c_int, [_P, C.c_uint32, _F, C.c_float, _F]),
+    "pbrt_us_apply_pulse": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _F, _F]),
 }
 
 _lib = None

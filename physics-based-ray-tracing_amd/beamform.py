@@ -63,6 +63,18 @@ def log_compress(env, dynamic_range=60.0) -> np.ndarray:
     return out
 
 
+def apply_pulse(traces, fs, frequency, sigma) -> np.ndarray:
+    """SURVEY f-3 pulse model (RayTracingV0.py:194-204): every trace (last axis) convolved with
+    h[k] = sin(2 pi f k / fs) exp(-(k / fs)^2 / sigma^2)  (pbrt_us_apply_pulse)."""
+    x = _capi.f32(np.asarray(traces))
+    T = x.shape[-1]
+    out = np.empty_like(x)
+    cx = _capi.default_context()
+    cx.check(cx.lib.pbrt_us_apply_pulse(cx.handle, x.size // T, T, float(fs), float(frequency), float(sigma), _capi.addr(x),
+                                        _capi.addr(out)), "pbrt_us_apply_pulse")
+    return out
+
+
 # ---- ultraspy-shaped front end (USMain.py:126-205) ---------------------------------------------------------------
 class Probe:
     def __init__(self, geometry_type, nb_elements, pitch, central_freq, bandwidth=70):

@@ -135,3 +135,32 @@ __global__ __launch_bounds__(256) void k_log_compress(uint32_t n, const float *_
     db = fminf(fmaxf(db, min_db), max_db);
     out[i] = (db - min_db) / dr;
 }
+
+// Pulse model (SURVEY f-3; RayTracingV0.py:194-204): every trace convolved with the Gaussian-windowed carrier
+// h[k] = sin(2 pi fc k / fs) * exp(-(k / fs)^2 / sigma^2), |k| <= K.  One workgroup per 256 output samples of one
+// trace: taps and the 256 + 2K input samples staged in LDS.  HBM-bound (4 B in, 4 B out per sample).
+#define PULSE_MAX_K 1024
+__global__ __launch_bounds__(256) void k_apply_pulse(uint32_t T, uint32_t K, float fs, float fc, float sigma,
+                                                     const float *__restrict__ in, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds_pulse[];
+    float *h = lds_pulse;            // [2K + 1], h[K + k]
+    float *x = lds_pulse + 2 * K + 1;  // [256 + 2K]
+    const uint32_t tr = blockIdx.y, n0 = blockIdx.x * 256u;
+    const float *src = in + (size_t)tr * T;
+    for (uint32_t i = threadIdx.x; i < 2 * K + 1; i += 256u) {
+        const float t = ((float)i - (float)K) / fs;
+        // phase reduced per cycle: sin(2 pi fc t) = sinpi(2 fc t)
+        h[i] = sinpif(2.0f * fc * t) * expf(-(t * t) / (sigma * sigma));
+    }
+    for (uint32_t i = threadIdx.x; i < 256u + 2 * K; i += 256u) {
+        const int64_t n = (int64_t)n0 + (int64_t)i - (int64_t)K;
+        x[i] = (n >= 0 && n < (int64_t)T) ? src[n] : 0.0f;
+    }
+    __syncthreads();
+    const uint32_t n = n0 + threadIdx.x;
+    if (n >= T) return;
+    float acc = 0.0f;
+    // out[n] = sum_k in[n - k] h[k]: x index of in[n - k] is threadIdx.x + K - k
+    for (uint32_t j = 0; j < 2 * K + 1; ++j) acc = fma_(x[threadIdx.x + 2 * K - j], h[j], acc);
+    out[(size_t)tr * T + n] = acc;
+}

@@ -167,7 +167,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                 amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                        // :341
                 float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);                 // :286-287,345
                 float fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;        // :345
-                float pressure = atten * amp * fd * sinf(phase);                       // :348
+                // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
+                float pressure = atten * amp * fd * ((a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase));  // :348
                 float tf = rintf(total_time * a.p.fs);                                 // :351-352
                 if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
                 if (tf >= 0.0f && tf < (float)T && visible) {                          // :353

@@ -1129,4 +1129,22 @@ int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic
     return S.finish();
 }
 
+int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
+                        const float *in, float *out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, in && out && in != out && fs > 0.0f && frequency > 0.0f && sigma > 0.0f);
+    NEED(ctx, (uint64_t)n_traces * time_samples < 0xffffffffull && n_traces <= 65535u);
+    const uint32_t K = (uint32_t)std::ceil(2.5 * (double)sigma * (double)fs);
+    NEED(ctx, K <= PULSE_MAX_K);
+    const uint32_t n = n_traces * time_samples;
+    LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
+    float *din = S.in(in, n), *dout = S.out<float>(n);
+    const size_t lds = (size_t)(2 * K + 1 + 256 + 2 * K) * 4;
+    (void)grid;
+    hipLaunchKernelGGL(k_apply_pulse, dim3(div_up(time_samples, 256), n_traces), block, lds, st, time_samples, K, fs, frequency,
+                       sigma, din, dout);
+    S.back(out, dout, n);
+    return S.finish();
+}
+
 }  // extern "C"

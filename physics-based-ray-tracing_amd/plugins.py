@@ -697,11 +697,24 @@ class UltraIntegrator(SamplingIntegrator):
         self.paths_per_ray = int(props.get("paths_per_ray", 1))
         self.seed = int(props.get("seed", 0))
         self.quirks = int(props.get("quirks", _capi.USQ_REFERENCE))
+        # SURVEY f-3: 'impulse' = the reference's one-sample p * sin(phase) (CustomIntegrator.py:348-354); 'gaussian' = the
+        # pulse of the prototype (RayTracingV0.py:194-204), length set by the otherwise unused wave_cycles:
+        # sigma = wave_cycles / (4 f)  [DEFINE]
+        self.pulse_model = str(props.get("pulse_model", "impulse"))
+        if self.pulse_model not in ("impulse", "gaussian"):
+            raise ValueError("pulse_model must be 'impulse' or 'gaussian'")
+        if self.pulse_model == "gaussian":
+            self.quirks |= _capi.USQ_NO_CARRIER
         self.max_path_len = 0.2  # CustomIntegrator.py:307,372
 
     def sample(self, scene, sampler, ray, medium=None, active=True):  # CustomIntegrator.py:52-53
         n = len(np.atleast_2d(np.asarray(ray["o"]))) if isinstance(ray, dict) else 1
         return np.zeros(n, np.float32), active, []
+
+    @property
+    def pulse_sigma(self) -> float:
+        """Gaussian width of the 'gaussian' pulse model: wave_cycles / (4 f) seconds  [DEFINE, SURVEY f-3]"""
+        return float(self.wave_cycles) / (4.0 * self.frequency)
 
     def us_params(self, scene, quirks=None) -> _capi.UsParams:
         if self.n_angles > _capi.US_MAX_ANGLES:
@@ -738,6 +751,10 @@ class UltraIntegrator(SamplingIntegrator):
                                                        _capi.addr(buf), _capi.addr(tx)), "pbrt_us_acquire")
         self.transmission_delays_buf = tx
         self.ray_count = int(dev.ctx.stats()["segments"])
+        if buf is not None and (int(p.quirks) & _capi.USQ_NO_CARRIER):
+            # f-3 pulse model: the echoes were deposited as plain amplitudes; give every trace the Gaussian-windowed carrier
+            from .beamform import apply_pulse
+            buf = apply_pulse(buf, self.fs, self.frequency, self.pulse_sigma)
         return buf
 
     def simulate_acquisition_parallel(self, scene):  # CustomIntegrator.py:235-405

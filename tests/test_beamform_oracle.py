@@ -83,3 +83,32 @@ def test_ultraspy_shaped_front_end(mi):
     with pytest.raises(KeyError):
         bf.update_setup("no_such_option", 1)
     assert "DelayAndSum" in str(bf)
+
+
+def test_pulse_model_of_an_impulse_is_the_pulse():
+    """RayTracingV0.py:194-198: amp * sin(2 pi fc (t - t0)) * exp(-(t - t0)^2 / sigma^2), on the sample grid"""
+    fs, fc, sigma = 50e6, 3e6, 5 / (4 * 3e6)
+    x = np.zeros((2, 600))
+    x[0, 300] = 2.0
+    x[1, 5] = 1.0                                # near the start: the pulse is cut off, not wrapped around
+    y = obf.apply_pulse(x, fs, fc, sigma)
+    t = (np.arange(600) - 300) / fs
+    want = 2.0 * np.sin(2 * np.pi * fc * t) * np.exp(-(t * t) / sigma ** 2)
+    K = int(np.ceil(2.5 * sigma * fs))
+    want[np.abs(np.arange(600) - 300) > K] = 0.0
+    assert np.allclose(y[0], want, atol=1e-12) and abs(y[0]).max() > 1.5
+    assert y[1, 599] == 0.0 and np.allclose(y[1, :5 + K + 1][::-1][:5], (np.sin(2 * np.pi * fc * (np.arange(K, K - 5, -1)) / fs)
+                                                                        * np.exp(-((np.arange(K, K - 5, -1)) / fs) ** 2 / sigma ** 2)), atol=1e-12)
+    # linear and shift invariant
+    x2 = np.roll(x[0], 40)
+    assert np.allclose(obf.apply_pulse(x2[None], fs, fc, sigma)[0], np.roll(y[0], 40), atol=1e-12)
+
+
+def test_pulse_model_option(mi):
+    from conftest import scene_path
+    ui = mi.load_file(scene_path("us_plate.xml")).integrator()
+    assert ui.pulse_model == "impulse" and not (ui.quirks & mi._capi.USQ_NO_CARRIER)
+    ug = mi.load_dict({"type": "ultrasound_integrator", "pulse_model": "gaussian", "frequency": 3e6, "wave_cycles": 5})
+    assert ug.quirks & mi._capi.USQ_NO_CARRIER and ug.pulse_sigma == pytest.approx(5 / (4 * 3e6))
+    with pytest.raises(ValueError):
+        mi.load_dict({"type": "ultrasound_integrator", "pulse_model": "square"})

@@ -125,3 +125,39 @@ def test_bmode_of_the_plate_and_fd_roughness_loop(mi):
         hist.append((rough, f0, grad))
         rough = float(np.clip(rough - 0.05 * np.sign(grad), 1e-4, 1.0))
     assert len(hist) == 3 and all(np.isfinite(h).all() for h in hist)
+
+
+def test_apply_pulse_matches_the_restatement(mi):
+    rng = np.random.default_rng(9)
+    x = np.zeros((6, 3000), np.float32)
+    idx = rng.integers(0, 3000, size=(6, 40))
+    for r in range(6):
+        x[r, idx[r]] = rng.normal(size=40).astype(np.float32)
+    x[0, 0] = 1.0
+    x[0, 2999] = -1.0                                                                       # pulses cut at both ends
+    for fs, fc, sigma in ((50e6, 3e6, 5 / (4 * 3e6)), (50e6, 5e6, 2 / (4 * 5e6)), (20e6, 1e6, 3e-6)):
+        got = mi.apply_pulse(x, fs, fc, sigma)
+        ref = obf.apply_pulse(x, fs, fc, sigma)
+        assert got.shape == x.shape and np.allclose(got, ref, rtol=0, atol=3e-5 * np.abs(ref).max())
+    with pytest.raises(RuntimeError):
+        mi.apply_pulse(x, 50e6, 3e6, 1e-3)                                                  # 125 000 taps: refused
+    big = rng.normal(size=(5 * 64, 10000)).astype(np.float32)                               # the channel buffer of config 3
+    a = mi.apply_pulse(big, 50e6, 3e6, 5 / (4 * 3e6))
+    assert np.allclose(mi.apply_pulse(2 * big, 50e6, 3e6, 5 / (4 * 3e6)), 2 * a, atol=1e-4 * np.abs(a).max())
+    assert np.allclose(a[17], obf.apply_pulse(big[17], 50e6, 3e6, 5 / (4 * 3e6)), atol=3e-5 * np.abs(a).max())
+
+
+def test_gaussian_pulse_acquisition_matches_the_oracle(mi, ob):
+    """pulse_model='gaussian': echoes deposited without the carrier (both sides), then the pulse on every trace"""
+    sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=64, seed=5)
+    ui = sc.integrator()
+    ref_impulse = ui._acquire(sc, ui.quirks)
+    q = ui.quirks | mi._capi.USQ_NO_CARRIER
+    got = ui._acquire(sc, q)
+    osc = ob.OracleScene.from_scene(sc)
+    amp, _ = osc.us_acquire(ui.us_params(sc, q), seed=5, paths_per_ray=64)
+    ref = obf.apply_pulse(amp, ui.fs, ui.frequency, ui.pulse_sigma)
+    assert got.shape == ref_impulse.shape == (5, 64, 10000)
+    assert np.linalg.norm(got - ref) <= 1e-3 * np.linalg.norm(ref) and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
+    # each echo now covers ~ wave_cycles * fs / f samples instead of one
+    assert (got != 0).sum() > 5 * (ref_impulse != 0).sum()

@@ -396,6 +396,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const uint64_t film_px = (uint64_t)f->crop_w * f->crop_h;
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (8u << 20);
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
+    s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
     NEED(c, npix_r * s_pass < 0xfffffc00ull);
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;

@@ -129,3 +129,62 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
     if world > 1:
         dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
     return buf if rank == 0 else None
+
+
+# ---- radiance mode, sharded by SAMPLES -------------------------------------------------------------------------------
+# The other natural split of a film of fixed size: every rank renders the WHOLE film with its own contiguous range of
+# the global sample indices (same RNG keys as the single-GPU render of all the samples) into un-normalised accumulators
+# (sum w*rgb, sum w; PBRT_FILM_RAW_ACCUM), ONE reduce(sum) of H*W*16 bytes adds them on rank 0, which divides.  Per-rank
+# work is exactly the single-GPU workload whatever the world size (no halo rows, no small crops, perfect balance), which
+# is what a weak-scaling run over spp wants; the sum of the partial accumulators differs from the sequential
+# accumulation only in the order of a few float additions (<= 1e-6 relative), so the image is deterministic for a given
+# world size but not bit-identical across world sizes -- the band split above is.
+def sample_ranges(spp: int, world_size: int):
+    """-> [(first_sample, count)] contiguous split of the sample index"""
+    return path_ranges(spp, world_size)
+
+
+def render_sample_shard(scene, spp, seed, rank, world_size, render_raw=None, device=None):
+    """This rank's samples of the whole film -> raw accumulators [H, W, 4] (float32 torch tensor).
+    render_raw(first_sample, count, out_tensor) fills the tensor; the default calls the HIP library on the tensor's
+    device memory."""
+    import torch
+
+    sens = scene.sensors()[0]
+    W, H = sens.film().size()
+    dev = device if device is not None else torch.device("cpu")
+    raw = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    first, count = sample_ranges(spp, world_size)[rank]
+    if count > 0:
+        if render_raw is not None:
+            render_raw(first, count, raw)
+        else:
+            if dev.type != "cuda":
+                raise RuntimeError("the HIP render path needs a device tensor (torch 'cuda' == HIP on ROCm)")
+            scene.integrator().render(scene, sensor=sens, seed=seed, spp=count, sample_offset=first, raw=True,
+                                      out_dev=raw.data_ptr())
+    return raw
+
+
+def reduce_film(raw, rank, world_size, group=None):
+    """ONE reduce(sum) of the raw accumulators to rank 0, then rgb / w.  -> [H, W, 3] tensor on rank 0, None elsewhere."""
+    import torch
+
+    if world_size > 1:
+        _dist().reduce(raw, dst=0, op=_dist().ReduceOp.SUM, group=group)
+        if rank != 0:
+            return None
+    w = raw[..., 3:4]
+    inv = torch.where(w > 0, 1.0 / w, torch.zeros_like(w))   # k_film_resolve: rgb * (w > 0 ? 1 / w : 0)
+    return raw[..., :3] * inv
+
+
+def distributed_render_samples(scene, spp, seed=0, render_raw=None, device=None, group=None):
+    """Whole job, sample-sharded: render this rank's samples, reduce on rank 0."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    raw = render_sample_shard(scene, spp, seed, rank, world, render_raw, device)
+    return reduce_film(raw, rank, world, group)

@@ -22,6 +22,7 @@ def test_band_layout_and_path_ranges():
     assert lay[0] == [(0, 16), (48, 16), (96, 4)] and par.rows_of(lay[0]) == 36
     assert par.band_layout(10, 4, 64) == [[(0, 10)], [], [], []]
     assert par.path_ranges(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)] and par.path_ranges(2, 4)[2:] == [(2, 0), (2, 0)]
+    assert par.sample_ranges(2048, 8) == [(256 * r, 256) for r in range(8)]
 
 
 def _worker(rank, world, port, tmp):
@@ -53,11 +54,18 @@ def _worker(rank, world, port, tmp):
         out.copy_(torch.from_numpy(buf))
 
     chan = par.distributed_acquire(us, paths_per_ray=9, seed=3, acquire=acquire)
+
+    def render_raw(first, count, out):      # sample-sharded split: the whole film, this rank's samples, raw accumulators
+        img, _ = oracle_render(ob, sc, 11, count, sample_offset=first, raw=True, n_threads=2)
+        out.copy_(torch.from_numpy(img))
+
+    film_s = par.distributed_render_samples(sc, spp=5, seed=11, render_raw=render_raw)
     if rank == 0:
         np.save(os.path.join(tmp, "film.npy"), film.numpy())
         np.save(os.path.join(tmp, "chan.npy"), chan.numpy())
+        np.save(os.path.join(tmp, "film_samples.npy"), film_s.numpy())
     else:
-        assert film is None and chan is None
+        assert film is None and chan is None and film_s is None
     dist.barrier()
     dist.destroy_process_group()
 
@@ -78,6 +86,9 @@ def test_two_rank_render_and_acquire_equal_single_rank(mi, ob, tmp_path):
     ref, _ = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 3, 9)
     got = np.load(tmp_path / "chan.npy")
     assert np.array_equal(got != 0, ref != 0) and np.allclose(got, ref, rtol=1e-5, atol=1e-9 * np.abs(ref).max())
+    # sample-sharded: ranks 0 / 1 rendered samples [0, 3) / [3, 5) of the whole film; one reduce(sum) of the accumulators
+    whole, _ = oracle_render(ob, sc, 11, 5)
+    assert np.allclose(np.load(tmp_path / "film_samples.npy"), whole, rtol=2e-6, atol=1e-7)
 
 
 def test_world_size_one_needs_no_process_group(mi, ob):

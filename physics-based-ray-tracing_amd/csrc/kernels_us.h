@@ -59,9 +59,25 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     __shared__ uint32_t wave_tot[2][SEG / 64];
     __shared__ uint32_t wave_seg[2][SEG / 64];
     constexpr uint32_t REGION = us_region_segs(ACCEL) * SEG;
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x, base = seg * REGION;  // seg: region index (see k_bounce)
-    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, REGION) : 0u) : a.seg_in[seg];
-    if (cnt_in == 0) {
+    constexpr bool WP = rad_wave_private(ACCEL);  // BVH scenes: per-wave compaction, no barrier per chunk (see k_bounce)
+    constexpr uint32_t W = SEG / 64, WREG = REGION / W, CH = WP ? 64u : SEG;
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x;  // seg: region index (see k_bounce)
+    const uint32_t lane_c = WP ? (tid & 63u) : tid;
+    const uint32_t own = WP ? seg * W + (tid >> 6) : seg;
+    const uint32_t base = WP ? seg * REGION + (tid >> 6) * WREG : seg * REGION;
+    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, WP ? WREG : REGION) : 0u) : a.seg_in[own];
+    if (WP) {
+        cnt_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_in);
+        uint32_t c = 0;
+        if ((tid & 63u) < W) {
+            const uint32_t b2 = seg * REGION + (tid & 63u) * WREG;
+            c = FIRST ? (a.n_paths > b2 ? 1u : 0u) : a.seg_in[seg * W + (tid & 63u)];
+        }
+        if (__ballot(c != 0) == 0) {  // no wave of the workgroup has work (same answer in every wave)
+            if ((tid & 63u) == 0) a.seg_out[own] = 0;
+            return;
+        }
+    } else if (cnt_in == 0) {
         if (tid == 0) a.seg_out[seg] = 0;
         return;
     }
@@ -87,10 +103,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     const uint32_t cap = a.cap;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
     uint32_t out_off = 0, ns_acc = 0;
-    for (uint32_t it0 = 0; it0 < cnt_in; it0 += SEG) {
+    for (uint32_t it0 = 0; it0 < cnt_in; it0 += CH) {
     const uint32_t buf = (it0 / SEG) & 1u;
-    const bool alive = it0 + tid < cnt_in;
-    const uint32_t slot = base + it0 + tid;
+    const bool alive = it0 + lane_c < cnt_in;
+    const uint32_t slot = base + it0 + lane_c;
     bool survive = false, did_seg = false;
     V3 o, d;
     float amp, atten, tof, geo_len;
@@ -198,17 +214,22 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     const unsigned long long bal = __ballot(survive);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
     const unsigned long long bseg = __ballot(did_seg);
-    if ((tid & 63) == 0) {
-        wave_tot[buf][wid] = (uint32_t)__popcll(bal);
-        wave_seg[buf][wid] = (uint32_t)__popcll(bseg);
-    }
-    __syncthreads();
     uint32_t off = 0, total = 0;
+    if (WP) {  // the wave packs its own survivors behind its own cursor
+        total = (uint32_t)__popcll(bal);
+        ns_acc += (uint32_t)__popcll(bseg);
+    } else {
+        if ((tid & 63) == 0) {
+            wave_tot[buf][wid] = (uint32_t)__popcll(bal);
+            wave_seg[buf][wid] = (uint32_t)__popcll(bseg);
+        }
+        __syncthreads();
 #pragma unroll
-    for (uint32_t w = 0; w < SEG / 64; ++w) {
-        uint32_t t = wave_tot[buf][w];
-        off += (w < wid) ? t : 0u;
-        total += t;
+        for (uint32_t w = 0; w < SEG / 64; ++w) {
+            uint32_t t = wave_tot[buf][w];
+            off += (w < wid) ? t : 0u;
+            total += t;
+        }
     }
     if (survive) {
         float *s = a.out + base + out_off + off + prefix;
@@ -225,7 +246,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         s[10 * cap] = __uint_as_float(home);
     }
     out_off += total;
-    if (tid == 0)
+    if (!WP && tid == 0)
         for (uint32_t w = 0; w < SEG / 64; ++w) ns_acc += wave_seg[buf][w];
     }  // chunk loop
     __syncthreads();  // all echoes of the workgroup are in the bins
@@ -233,9 +254,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         const uint32_t ci = agg_idx[t];
         if (ci != 0xffffffffu) atomicAdd(&a.channel[ci], agg_sum[t]);
     }
-    if (tid == 0) {
-        a.seg_out[seg] = out_off;
-        unsigned long long *row = a.stats + seg;  // per-region rows, see k_bounce
+    if (WP ? (tid & 63u) == 0 : tid == 0) {
+        a.seg_out[own] = out_off;
+        unsigned long long *row = a.stats + own;  // per-region / per-wave rows, see k_bounce
         const size_t stride = a.stat_stride;
         row[0] += ns_acc;
         row[stride] += ns_acc;  // one occlusion ray per shaded segment

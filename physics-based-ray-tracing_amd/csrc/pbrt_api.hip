@@ -743,10 +743,11 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
-    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)nseg * 4);
-    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)nseg * 4);
+    const uint32_t n_own = nseg * rad_owners_per_region(s->accel_kernel);  // live counters / statistics rows (render_impl)
+    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
+    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * nseg * 8;  // per-segment rows, reduced at the end
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
@@ -765,7 +766,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     a.sc = s->ds;
     a.p = *p;
     a.stats = segstats;
-    a.stat_stride = nseg;
+    a.stat_stride = n_own;
     a.channel = d_channel;
     a.tx = d_tx;
     a.dir0 = d_dir;
@@ -826,7 +827,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, nseg, (size_t)nseg, dstats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

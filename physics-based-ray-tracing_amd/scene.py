@@ -241,26 +241,53 @@ class RectangleShape(Shape):
 class ConeShape(Shape):
     """'cone' (MitsubaScenes/Cone_Box.xml:36-47, Cone_FLoating.xml) has no Mitsuba-3 definition.
     [DEFINE]: the closed unit cone -- apex (0, 0, 1), base disc of radius 1
-    in the plane z = 0 -- under to_world, tessellated on the host into `segments` lateral triangles plus a
-    `segments`-triangle base fan (outward face normals), so it takes the BVH path like any other mesh and
-    non-uniform to_world scales (Cone_Box.xml: 0.06 / 0.06 / 0.10) need no special case."""
+    in the plane z = 0 -- under to_world, tessellated on the host (outward face normals), so it takes the BVH
+    path like any other mesh and non-uniform to_world scales (Cone_Box.xml: 0.06 / 0.06 / 0.10) need no special
+    case.  `segments` around the axis, `rings` along it and across the base disc: plain fans from the apex / the
+    centre are 2 x `segments` slivers whose boxes all overlap (measured: 3 x slower traversal than the ring scene
+    with 4 x fewer triangles), so both surfaces are cut into rings of quads with a fan only in the innermost ring."""
 
     def __init__(self, props):
         super().__init__(props)
-        self.segments = int(props.get("segments", 96))
-        if self.segments < 3:
-            raise ValueError("cone: segments must be >= 3")
+        self.segments = int(props.get("segments", 64))
+        self.rings = int(props.get("rings", 4))
+        if self.segments < 3 or self.rings < 1:
+            raise ValueError("cone: segments must be >= 3 and rings >= 1")
 
     def primitives(self):
-        n = self.segments
+        n, R = self.segments, self.rings
         ang = 2.0 * np.pi * np.arange(n, dtype=np.float64) / n
-        ring = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], axis=1)
-        nxt = np.roll(ring, -1, axis=0)
+        c, s = np.cos(ang), np.sin(ang)
+
+        def ring(radius, z):
+            return np.stack([radius * c, radius * s, np.full(n, z)], axis=1)
+
+        tris = []  # (v0, v1, v2) arrays [n, 3]
         apex = np.tile(np.array([[0.0, 0.0, 1.0]]), (n, 1))
         centre = np.zeros((n, 3))
-        v0 = np.concatenate([apex, centre])   # lateral (apex, p_i, p_i+1); base (centre, p_i+1, p_i): normal -z
-        v1 = np.concatenate([ring, nxt])
-        v2 = np.concatenate([nxt, ring])
+        for k in range(R):       # lateral surface, level k -> k + 1 (z = k / R, radius 1 - z)
+            lo = ring(1.0 - k / R, k / R)
+            lo1 = np.roll(lo, -1, axis=0)
+            if k == R - 1:
+                tris.append((lo, lo1, apex))
+            else:
+                hi = ring(1.0 - (k + 1) / R, (k + 1) / R)
+                hi1 = np.roll(hi, -1, axis=0)
+                tris.append((lo, lo1, hi1))
+                tris.append((lo, hi1, hi))
+        for k in range(R):       # base disc (normal -z), radius k / R -> (k + 1) / R
+            out = ring((k + 1) / R, 0.0)
+            out1 = np.roll(out, -1, axis=0)
+            if k == 0:
+                tris.append((centre, out1, out))
+            else:
+                inn = ring(k / R, 0.0)
+                inn1 = np.roll(inn, -1, axis=0)
+                tris.append((inn, out1, out))
+                tris.append((inn, inn1, out1))
+        v0 = np.concatenate([t[0] for t in tris])
+        v1 = np.concatenate([t[1] for t in tris])
+        v2 = np.concatenate([t[2] for t in tris])
         T = self.to_world
         v0, v1, v2 = T.transform_affine(v0), T.transform_affine(v1), T.transform_affine(v2)
         if (np.linalg.det(T.matrix[:3, :3]) < 0) != self.flip_normals:

@@ -220,24 +220,32 @@ def test_unknown_plugin_is_loud(mi):
 
 def test_cone_definition(mi):
     """'cone' = closed unit cone (apex (0,0,1), base disc r = 1 at z = 0) under to_world, tessellated."""
-    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "segments": 64}})
+    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "segments": 64, "rings": 1}})   # plain fans
     P = sc.flatten()["prims"]
     assert len(P) == 128 and np.all(P["type"] == 0)
     v0, e1, e2, n = (P["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6, 9))
-    assert np.allclose(v0[:64], [0, 0, 1]) and np.allclose(v0[64:], [0, 0, 0])            # lateral fan from the apex, base fan
-    assert np.allclose(np.linalg.norm((v0 + e1)[:, :2], axis=1), 1) and np.allclose((v0 + e1)[:, 2], 0)
-    assert np.allclose(n[64:], [0, 0, -1]) and np.all(n[:64, 2] > 0)                      # outward normals
-    mid = v0[:64] + (e1[:64] + e2[:64]) / 3
-    assert np.all(np.einsum("ij,ij->i", n[:64, :2], mid[:, :2]) > 0)
-    vol = np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6                          # divergence theorem: closed, outward
-    assert vol == pytest.approx(np.pi / 3, rel=2e-3)
+    assert np.allclose((v0 + e2)[:64], [0, 0, 1]) and np.allclose(v0[64:], [0, 0, 0])    # lateral fan to the apex, base fan
+    assert np.allclose(np.linalg.norm(v0[:64, :2], axis=1), 1) and np.allclose(v0[:64, 2], 0)
+    for kw in (dict(segments=64, rings=1), dict(), dict(segments=24, rings=5)):           # default: 64 segments x 4 rings
+        P = mi.load_dict({"type": "scene", "c": {"type": "cone", **kw}}).flatten()["prims"]
+        S, R = kw.get("segments", 64), kw.get("rings", 4)
+        assert len(P) == 2 * S * (2 * R - 1)
+        v0, e1, e2, n = (P["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6, 9))
+        base = n[:, 2] < -0.5
+        assert base.sum() == len(P) // 2 and np.allclose(n[base], [0, 0, -1]) and np.all(n[~base, 2] > 0)   # outward normals
+        mid = v0 + (e1 + e2) / 3
+        assert np.all(np.einsum("ij,ij->i", n[~base, :2], mid[~base, :2]) > 0) and np.allclose(mid[base, 2], 0)
+        assert np.allclose(np.hypot(mid[~base, 0], mid[~base, 1]), 1 - mid[~base, 2], atol=0.05)            # on the cone
+        vol = np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6                      # divergence theorem: closed, outward
+        assert vol == pytest.approx(np.pi / 3, rel=2.5e-2 if S < 64 else 2e-3)
     # the reference's phantom (intent transform, SURVEY App. E): base centre, apex, non-uniform scale
     sc = mi.load_file(scene_path("us_cone_box.xml"))
     P = sc.flatten()["prims"]
     c = P[P["shape"] == [s.id() for s in sc.shapes()].index("cone")]
-    assert len(c) == 192 and len(P) == 197
-    assert np.allclose(c["g"][0, 0:3], [0.0422618, 0.0309976, 0.1451651], atol=1e-6)     # apex = base + axis image
-    assert np.allclose(c["g"][96, 0:3], [0, 0, 0.06], atol=1e-7)
+    assert len(c) == 896 and len(P) == 901
+    corners = np.concatenate([c["g"][:, 0:3], c["g"][:, 0:3] + c["g"][:, 3:6], c["g"][:, 0:3] + c["g"][:, 6:9]])
+    assert np.abs(corners - [0.0422618, 0.0309976, 0.1451651]).sum(axis=1).min() < 1e-6   # apex = base + axis image
+    assert np.abs(corners - [0, 0, 0.06]).sum(axis=1).min() < 1e-7                         # base centre
     v0, e1, e2 = (c["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6))
     assert np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6 == pytest.approx(np.pi * 0.06 * 0.06 * 0.10 / 3, rel=2e-3)
     # a mirrored to_world keeps the normals outward
@@ -258,4 +266,4 @@ def test_reference_phantoms_all_load(mi):
         P = sc.flatten()["prims"]
         assert len(P) >= 1 and type(sc.integrator()).__name__ == "UltraIntegrator"
         if "Cone" in f:
-            assert (P["type"] == 0).sum() == 192
+            assert (P["type"] == 0).sum() == 896

@@ -5,7 +5,7 @@ cat > /tmp/us_run.py <<PY
 import os, sys
 sys.path.insert(0, "$ROOT")
 import pbrt_amd as mi
-us = mi.load_file("$ROOT/tests/scenes/us_sphere_box.xml")
+us = mi.load_file(os.environ.get("US_SCENE", "$ROOT/tests/scenes/us_sphere_box.xml"))
 ui = us.integrator()
 for i in range(2):
     ui._acquire(us, ui.quirks, paths_per_ray=int(os.environ.get("PPR", "65536")))

@@ -31,7 +31,7 @@
 // barrier puts the 16 waves of a brute-force radiance workgroup in lock-step (cbox: 12.3 -> 15.6 ms), so
 // that variant keeps one chunk per workgroup.
 #ifndef REGION_SEGS_BVH
-#define REGION_SEGS_BVH 8
+#define REGION_SEGS_BVH 4
 #endif
 #ifndef REGION_SEGS_US
 #define REGION_SEGS_US 8
@@ -67,8 +67,24 @@ __host__ __device__ constexpr bool rad_wave_private(int accel) {
     return accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS;
 #endif
 }
-// live-path counters / statistics rows per region (one per workgroup, or one per wave)
+// Radiance BVH kernels go one step further: the waves of a workgroup take their 64-path chunks from a queue in LDS
+// (one returning ds_add per chunk) and reserve the slots of their survivors with another, so the region is one
+// compaction domain again and the waves of a workgroup finish together -- with fixed 512-slot shares a wave with
+// expensive rays kept its workgroup (and the 114 KB LDS image) alive while the other 15 had long left
+// (measured: 2.3 of 4 possible waves per SIMD).
+__host__ __device__ constexpr bool rad_dynamic(int accel) {
+#ifdef PBRT_BVH_STATIC_WAVES  // diagnostic builds only (A/B against fixed per-wave shares)
+    return false && accel;
+#else
+    return rad_wave_private(accel);
+#endif
+}
+// live-path counters per region of the radiance kernels (one per workgroup, or one per wave with fixed shares)
 __host__ __device__ constexpr uint32_t rad_owners_per_region(int accel) {
+    return (rad_wave_private(accel) && !rad_dynamic(accel)) ? seg_threads(accel) / 64 : 1;
+}
+// statistics rows per region (per workgroup, or per wave)
+__host__ __device__ constexpr uint32_t rad_rows_per_region(int accel) {
     return rad_wave_private(accel) ? seg_threads(accel) / 64 : 1;
 }
 #define TAB_MAX 32
@@ -214,12 +230,21 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const uint32_t seg = blockIdx.x;  // region index
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REGION = rad_region_segs(ACCEL) * SEG;
-    constexpr bool WP = rad_wave_private(ACCEL);       // per-wave compaction (BVH kernels)
-    constexpr uint32_t W = SEG / 64, WREG = REGION / W;  // waves per workgroup, slots owned by one wave
-    constexpr uint32_t CH = WP ? 64u : SEG;            // paths per chunk of the walk
-    const uint32_t lane_c = WP ? (tid & 63u) : tid;    // position inside the chunk
-    const uint32_t own = WP ? seg * W + (tid >> 6) : seg;  // live counter / statistics row of this wave / workgroup
+    constexpr bool DYN = rad_dynamic(ACCEL);                  // chunk queue + slot reservation in LDS (BVH kernels)
+    constexpr bool WP = rad_wave_private(ACCEL) && !DYN;      // fixed per-wave shares (diagnostic fallback)
+    constexpr bool PERWAVE = WP || DYN;                       // the waves walk 64-path chunks on their own
+    constexpr uint32_t W = SEG / 64, WREG = REGION / W;       // waves per workgroup, slots owned by one wave (WP)
+    constexpr uint32_t CH = PERWAVE ? 64u : SEG;              // paths per chunk of the walk
+    const uint32_t lane_c = PERWAVE ? (tid & 63u) : tid;      // position inside the chunk
+    const uint32_t own = WP ? seg * W + (tid >> 6) : seg;     // live counter of this wave / workgroup
+    const uint32_t row_id = PERWAVE ? seg * W + (tid >> 6) : seg;  // statistics row
     const uint32_t base = WP ? seg * REGION + (tid >> 6) * WREG : seg * REGION;
+    __shared__ uint32_t q_in, q_out, q_done;                  // DYN: next chunk, next free output slot, finished waves
+    if (DYN && tid == 0) {
+        q_in = 0;
+        q_out = 0;
+        q_done = 0;
+    }
     uint32_t cnt_in;
     if (FIRST) {
         cnt_in = a.n_paths > base ? min(a.n_paths - base, WP ? WREG : REGION) : 0u;
@@ -242,6 +267,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         if (tid == 0) a.seg_out[seg] = 0;
         return;
     }
+    if (DYN) cnt_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_in);
     // Waves without a live path leave at once instead of idling until the compaction barrier: their wave slots
     // are free for the next workgroup's waves (late bounces run at 10-50 % fill).  They publish a zero survivor
     // count first; s_barrier does not wait for terminated waves.
@@ -266,7 +292,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     }
     const uint32_t live_threads = early_exit ? (min(cnt_in, SEG) + 63u) & ~63u : SEG;  // waves still present
     LdsScene ls = {nullptr, nullptr, nullptr};
-    if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
+    if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
+    if (DYN && ACCEL != ACCEL_K_BVH_LDS) __syncthreads();               // publishes the queue words
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     if (ACCEL == ACCEL_K_BRUTE && FIRST) fill_tables_lds(a.sc, tab_lds, SEG);
@@ -275,9 +302,15 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
     const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
     uint32_t out_off = 0;      // survivors written so far (front of this region of the `out` state)
-    uint32_t ns_acc = 0, nh_acc = 0;
+    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0;
     // the region's live paths sit compacted at its front: walk them SEG at a time; dead slots cost nothing
     for (uint32_t it0 = 0; it0 < (REGION > SEG ? cnt_in : 1u); it0 += CH) {  // single trip when REGION == SEG
+    if (DYN) {  // take the next 64-path chunk of the region from the workgroup's queue
+        uint32_t nxt = 0;
+        if ((tid & 63u) == 0) nxt = atomicAdd(&q_in, 64u);
+        it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
+        if (it0 >= cnt_in) break;
+    }
     const uint32_t buf = (it0 / SEG) & 1u;
     const bool alive = it0 + lane_c < cnt_in;
     const uint32_t slot = base + it0 + lane_c;
@@ -412,7 +445,15 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
     const unsigned long long bseg = __ballot(did_seg), bshd = __ballot(did_shadow);
     uint32_t off = 0, total = 0;
-    if (WP) {  // the wave packs its own survivors behind its own cursor: no LDS, no barrier
+    if (DYN) {  // reserve the survivors' slots in the region with one returning LDS atomic per wave and chunk
+        const uint32_t cnt_w = (uint32_t)__popcll(bal);
+        uint32_t got = 0;
+        if ((tid & 63u) == 0 && cnt_w) got = atomicAdd(&q_out, cnt_w);
+        off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        ns_acc += (uint32_t)__popcll(bseg);
+        nh_acc += (uint32_t)__popcll(bshd);
+        live_acc += (uint32_t)__popcll(__ballot(alive));
+    } else if (WP) {  // the wave packs its own survivors behind its own cursor: no LDS, no barrier
         total = (uint32_t)__popcll(bal);
         ns_acc += (uint32_t)__popcll(bseg);
         nh_acc += (uint32_t)__popcll(bshd);
@@ -454,19 +495,31 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         bst(r_out, v4 + 14 * row, 0, __uint_as_float(home));
     }
     out_off += total;
-    if (!WP && tid == 0) {
+    if (!PERWAVE && tid == 0) {
         for (uint32_t w = 0; w < SEG / 64; ++w) {
             ns_acc += wave_seg[buf][w];
             nh_acc += wave_shd[buf][w];
         }
     }
     }  // chunk loop
+    if (DYN) {
+        if ((tid & 63u) == 0) {
+            unsigned long long *row = a.stats + row_id;  // per-wave statistics rows
+            const size_t stride = a.stat_stride;
+            row[0] += ns_acc;
+            row[stride] += nh_acc;
+            row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += live_acc;
+            // the last wave to finish publishes the region's survivor count (LDS atomics of one CU are ordered)
+            if (atomicAdd(&q_done, 1u) == W - 1) a.seg_out[seg] = atomicAdd(&q_out, 0u);
+        }
+        return;
+    }
     if (WP ? (tid & 63u) == 0 : tid == 0) {
         a.seg_out[own] = out_off;
         // per-region statistics rows (plain read-modify-write by the owning workgroup; launches of a
         // call are ordered on the stream).  NOT global atomics: 3 same-line atomics per workgroup
         // serialise at ~12 ns each and were the whole kernel time (DESIGN.md "What did not work").
-        unsigned long long *row = a.stats + own;
+        unsigned long long *row = a.stats + row_id;
         const size_t stride = a.stat_stride;
         row[0] += ns_acc;
         row[stride] += nh_acc;
@@ -720,14 +773,14 @@ __global__ __launch_bounds__(1024) void k_scan_owners(const uint32_t *cnt, uint3
     for (uint32_t i = lo; i < hi; ++i) cnt_new[i] = total > i * quota ? min(total - i * quota, quota) : 0u;
 }
 
-// one wave per source owner
+// one workgroup per source owner
 __global__ __launch_bounds__(256) void k_repack_copy(const float *__restrict__ in, float *__restrict__ out,
                                                      const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ offs,
                                                      const uint32_t *__restrict__ quota_p, uint32_t n_own, uint32_t wreg) {
-    const uint32_t own = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t own = blockIdx.x;
     if (own >= n_own) return;
     const uint32_t n = cnt[own], dense0 = offs[own], src0 = own * wreg, quota = *quota_p;
-    for (uint32_t j = lane; j < n; j += 64u) {
+    for (uint32_t j = threadIdx.x; j < n; j += 256u) {
         const uint32_t dense = dense0 + j, o2 = dense / quota, p2 = dense - o2 * quota;
         const float *s = in + (state_voff(src0 + j) >> 2);
         float *d = out + (state_voff(o2 * wreg + p2) >> 2);

@@ -52,6 +52,11 @@ __host__ __device__ constexpr uint32_t us_waves_per_eu(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? seg_waves_per_eu(accel) : US_WAVES_PER_EU;
 }
 
+// live counters / statistics rows per region of the ultrasound kernels (per wave for the BVH variants)
+__host__ __device__ constexpr uint32_t us_owners_per_region(int accel) {
+    return rad_wave_private(accel) ? seg_threads(accel) / 64 : 1;
+}
+
 template <bool FIRST, int ACCEL>
 __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
     constexpr uint32_t SEG = seg_threads(ACCEL);

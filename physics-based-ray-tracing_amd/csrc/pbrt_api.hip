@@ -417,7 +417,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t *quota = repack ? (uint32_t *)c->buf("seg_quota", 64) : nullptr;
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
+    const uint32_t n_rows = nseg * rad_rows_per_region(s->accel_kernel);         // statistics rows
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_rows * 8;  // reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
@@ -437,7 +438,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.cam = *cam;
         a.Lhome = Lhome;
         a.stats = segstats;
-        a.stat_stride = n_own;
+        a.stat_stride = n_rows;
         a.cap = cap;
         a.n_paths = (uint32_t)(npix_r * sc);
         a.max_depth = f->max_depth;
@@ -470,7 +471,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 const uint32_t owners = rad_owners_per_region(s->accel_kernel), wreg = REGION / owners;
                 hipLaunchKernelGGL(k_scan_owners, dim3(1), dim3(1024), 0, st, sin, n_own, wreg, owners, (uint32_t)c->n_cu, offs, segC,
                                    quota);
-                hipLaunchKernelGGL(k_repack_copy, dim3(div_up(n_own, 4)), dim3(256), 0, st, in, stC, sin, offs, quota, n_own, wreg);
+                hipLaunchKernelGGL(k_repack_copy, dim3(n_own), dim3(256), 0, st, in, stC, sin, offs, quota, n_own, wreg);
                 a.in = stC;
                 a.seg_in = segC;
             }
@@ -532,7 +533,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_rows, (size_t)n_rows, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -601,7 +602,8 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
+    const uint32_t n_rows = nseg * rad_rows_per_region(s->accel_kernel);
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_rows * 8;  // rows, reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
@@ -619,7 +621,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     a.sc = s->ds;
     a.Lhome = Lhome;
     a.stats = segstats;
-    a.stat_stride = n_own;
+    a.stat_stride = n_rows;
     a.cap = cap;
     a.n_paths = n;
     a.max_depth = max_depth;
@@ -743,7 +745,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
-    const uint32_t n_own = nseg * rad_owners_per_region(s->accel_kernel);  // live counters / statistics rows (render_impl)
+    const uint32_t n_own = nseg * us_owners_per_region(s->accel_kernel);  // live counters / statistics rows
     uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
     uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);

@@ -51,7 +51,7 @@ extern "C" {
 #define PBRT_PRIM_TRIANGLE 0u
 #define PBRT_PRIM_SPHERE 1u
 #define PBRT_PRIM_PARALLELOGRAM 2u
-#define PBRT_PRIM_CONE 3u
+/* ('cone' shapes are tessellated into triangles by the host layer; there is no analytic cone primitive.) */
 
 typedef struct pbrt_prim {
     float g[12];

@@ -106,7 +106,7 @@ inline bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float
         *v = vs * inv;
         return true;
     }
-    return false;  // CONE: not built yet
+    return false;  // unknown primitive type (cones arrive as triangles)
 }
 
 // Brute-force scenes (<= 32 primitives, walked in index order by every ray): candidate hit as the

@@ -596,18 +596,25 @@ __global__ __launch_bounds__(256) void k_film_accum(const FilmArgs a) {
     a.acc[3 * npx + idx] = aw;
 }
 
-// Tiled form for the tent / gaussian filters: a 16 x 16 pixel tile per workgroup.  Per sample index the
+// Tiled form for the tent / gaussian filters: a TILE x TILE pixel tile per workgroup (16; 8 when the crop has too
+// few 16 x 16 tiles to fill the GPU -- the sample loop of a tile is sequential, and e.g. one rank's 512 x 64 band
+// of an 8-GPU job at 2048 spp spent 4.9 of 13.5 ms in 128 workgroups).  Per sample index the
 // workgroup evaluates the jitter hash ONCE per pixel of the haloed tile (not once per gathering
 // neighbour: 1.3 instead of 9 / 25 hashes per thread) and stages (film x, film y, r, g, b) in LDS; every
 // thread then gathers its (2R+1)^2 neighbourhood from LDS in the same fixed order as k_film_accum, so the
 // sums are bit-identical.  Double-buffered: one barrier per sample.
-#define FILM_TILE 16
 #define FILM_RMAX 2
-#define FILM_TW (FILM_TILE + 2 * FILM_RMAX)
+template <int FILM_TILE, int FILTER>  // the filter is a template parameter: radius and tap loops are compile-time
 __global__ __launch_bounds__(FILM_TILE *FILM_TILE) void k_film_accum_tiled(const FilmArgs a) {
-    __shared__ float tile[2][FILM_TW * FILM_TW][5];
-    const int R = a.filter == PBRT_FILTER_TENT ? 1 : 2;
-    const int TW = FILM_TILE + 2 * R;
+    constexpr int FILM_TW = FILM_TILE + 2 * FILM_RMAX;
+    // LDS image of the haloed tile, one plane per component, rows padded to a stride that puts the rows a half-wave
+    // reads at once (32 lanes: 2 rows of 16 / 4 rows of 8) on disjoint banks (AoS [entry][5] measured 39 % of the LDS
+    // cycles in bank conflicts)
+    constexpr int LS = FILM_TILE == 16 ? 48 : 40;
+    static_assert(LS >= FILM_TW, "row stride covers the haloed row");
+    __shared__ float tile[2][5][FILM_TW * LS];
+    constexpr int R = FILTER == PBRT_FILTER_TENT ? 1 : 2;
+    constexpr int TW = FILM_TILE + 2 * R;
     const uint32_t tid = threadIdx.y * FILM_TILE + threadIdx.x;
     const int tx0 = (int)(a.cx0 + blockIdx.x * FILM_TILE), ty0 = (int)(a.cy0 + blockIdx.y * FILM_TILE);  // film coords of the tile
     const int x = tx0 + (int)threadIdx.x, y = ty0 + (int)threadIdx.y;
@@ -622,17 +629,19 @@ __global__ __launch_bounds__(FILM_TILE *FILM_TILE) void k_film_accum_tiled(const
         aw = a.acc[3 * npx + idx];
     }
     const float ccx = (float)x + 0.5f, ccy = (float)y + 0.5f;
-    // staging duty of this thread: haloed-tile entries tid and tid + 256 (TW * TW <= 400); everything that does not
+    // staging duty of this thread: haloed-tile entries tid, tid + NT, ... (NST of them); everything that does not
     // depend on the sample index is computed once, and the radiance record of sample sl + 1 is requested before
     // sample sl is staged and gathered, so the HBM / L2 round trip is off the per-sample critical path
-    constexpr int NT = FILM_TILE * FILM_TILE;
-    bool st_in[2], st_valid[2];
-    uint32_t st_key[2], st_k[2];
-    float st_x[2], st_y[2];
+    constexpr int NT = FILM_TILE * FILM_TILE, NST = (FILM_TW * FILM_TW + NT - 1) / NT;
+    bool st_in[NST], st_valid[NST];
+    uint32_t st_key[NST], st_k[NST];
+    float st_x[NST], st_y[NST];
+    int st_lds[NST];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NST; ++j) {
         const int i = (int)tid + j * NT;
         const int nx = tx0 - R + i % TW, ny = ty0 - R + i / TW;
+        st_lds[j] = (i / TW) * LS + i % TW;
         st_in[j] = i < TW * TW;
         st_valid[j] = st_in[j] && nx >= (int)a.rx0 && ny >= (int)a.ry0 && nx < (int)(a.rx0 + a.rw) && ny < (int)(a.ry0 + a.rh);
         st_key[j] = (uint32_t)ny * a.film_w + (uint32_t)nx;
@@ -642,47 +651,58 @@ __global__ __launch_bounds__(FILM_TILE *FILM_TILE) void k_film_accum_tiled(const
     }
     const float4 *Lrec = reinterpret_cast<const float4 *>(a.Lhome);
     const float4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float4 Lcur[2];
+    // radiance records of the next PF samples, requested PF iterations ahead: one iteration is shorter than an HBM / L2
+    // round trip (with a distance of one the loop ran at 2.3 us per sample whatever the workgroup count)
+    constexpr int PF = 4;
+    float4 Lq[PF][NST];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) Lcur[j] = (st_valid[j] && a.s_count > 0) ? Lrec[st_k[j]] : zero4;
-    for (uint32_t sl = 0; sl < a.s_count; ++sl) {
-        const uint32_t s_idx = a.s_first + sl;
-        float(*T)[5] = tile[sl & 1];
-        float4 Lnext[2];
+    for (int u = 0; u < PF; ++u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            Lnext[j] = (st_valid[j] && sl + 1 < a.s_count) ? Lrec[(size_t)(sl + 1) * a.npix_r + st_k[j]] : zero4;
+        for (int j = 0; j < NST; ++j)
+            Lq[u][j] = (st_valid[j] && (uint32_t)u < a.s_count) ? Lrec[(size_t)u * a.npix_r + st_k[j]] : zero4;
+    for (uint32_t sl0 = 0; sl0 < a.s_count; sl0 += PF) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (!st_in[j]) continue;
-            const int i = (int)tid + j * NT;
-            float px = 1e30f, py = 1e30f;  // outside the film / rendered region: weight 0
-            if (st_valid[j]) {
-                F4 uj = rng4(st_key[j], s_idx, 0, a.seed);
-                px = st_x[j] + uj.x;
-                py = st_y[j] + uj.y;
-            }
-            T[i][0] = px;
-            T[i][1] = py;
-            T[i][2] = Lcur[j].x;
-            T[i][3] = Lcur[j].y;
-            T[i][4] = Lcur[j].z;
-        }
-        Lcur[0] = Lnext[0];
-        Lcur[1] = Lnext[1];
-        __syncthreads();
-        if (inside) {
-            for (int dy = 0; dy <= 2 * R; ++dy)
-                for (int dx = 0; dx <= 2 * R; ++dx) {
-                    const float *e = T[((int)threadIdx.y + dy) * TW + (int)threadIdx.x + dx];
-                    float w = filter_1d(a.filter, ccx - e[0]) * filter_1d(a.filter, ccy - e[1]);
-                    if (w > 0.0f) {
-                        ar = fma_(w, e[2], ar);
-                        ag = fma_(w, e[3], ag);
-                        ab = fma_(w, e[4], ab);
-                        aw += w;
-                    }
+        for (int u = 0; u < PF; ++u) {
+            const uint32_t sl = sl0 + (uint32_t)u;
+            if (sl >= a.s_count) break;
+            const uint32_t s_idx = a.s_first + sl;
+            float(*T)[FILM_TW * LS] = tile[sl & 1];
+#pragma unroll
+            for (int j = 0; j < NST; ++j) {
+                if (!st_in[j]) continue;
+                const int i = st_lds[j];
+                float px = 1e30f, py = 1e30f;  // outside the film / rendered region: weight 0
+                if (st_valid[j]) {
+                    F4 uj = rng4(st_key[j], s_idx, 0, a.seed);
+                    px = st_x[j] + uj.x;
+                    py = st_y[j] + uj.y;
                 }
+                T[0][i] = px;
+                T[1][i] = py;
+                T[2][i] = Lq[u][j].x;
+                T[3][i] = Lq[u][j].y;
+                T[4][i] = Lq[u][j].z;
+            }
+#pragma unroll
+            for (int j = 0; j < NST; ++j)
+                Lq[u][j] = (st_valid[j] && sl + PF < a.s_count) ? Lrec[(size_t)(sl + PF) * a.npix_r + st_k[j]] : zero4;
+            __syncthreads();
+            if (inside) {
+                const int e0 = (int)threadIdx.y * LS + (int)threadIdx.x;
+#pragma unroll
+                for (int dy = 0; dy <= 2 * R; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx <= 2 * R; ++dx) {
+                        const int e = e0 + dy * LS + dx;
+                        float w = filter_1d(FILTER, ccx - T[0][e]) * filter_1d(FILTER, ccy - T[1][e]);
+                        if (w > 0.0f) {
+                            ar = fma_(w, T[2][e], ar);
+                            ag = fma_(w, T[3][e], ag);
+                            ab = fma_(w, T[4][e], ab);
+                            aw += w;
+                        }
+                    }
+            }
         }
     }
     if (inside) {

@@ -523,9 +523,20 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         fa.seed = f->seed;
         if (f->filter == PBRT_FILTER_BOX)
             hipLaunchKernelGGL(k_film_accum, dim3(div_up(film_px, 256)), dim3(256), 0, st, fa);
-        else
-            hipLaunchKernelGGL(k_film_accum_tiled, dim3(div_up(f->crop_w, FILM_TILE), div_up(f->crop_h, FILM_TILE)),
-                               dim3(FILM_TILE, FILM_TILE), 0, st, fa);
+        else {
+            // small crops: 4 x as many (single-wave) workgroups; same sums, pixel by pixel
+            const bool big = (uint64_t)div_up(f->crop_w, 16) * div_up(f->crop_h, 16) >= 4ull * (uint64_t)c->n_cu;
+            const bool tent = f->filter == PBRT_FILTER_TENT;
+            const dim3 g16(div_up(f->crop_w, 16), div_up(f->crop_h, 16)), g8(div_up(f->crop_w, 8), div_up(f->crop_h, 8));
+            if (big && tent)
+                hipLaunchKernelGGL((k_film_accum_tiled<16, PBRT_FILTER_TENT>), g16, dim3(16, 16), 0, st, fa);
+            else if (big)
+                hipLaunchKernelGGL((k_film_accum_tiled<16, PBRT_FILTER_GAUSSIAN>), g16, dim3(16, 16), 0, st, fa);
+            else if (tent)
+                hipLaunchKernelGGL((k_film_accum_tiled<8, PBRT_FILTER_TENT>), g8, dim3(8, 8), 0, st, fa);
+            else
+                hipLaunchKernelGGL((k_film_accum_tiled<8, PBRT_FILTER_GAUSSIAN>), g8, dim3(8, 8), 0, st, fa);
+        }
         HIPCHK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(k_film_resolve, dim3(div_up(film_px, 256)), dim3(256), 0, st, acc, (float *)d_out, (uint32_t)film_px,

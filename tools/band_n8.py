@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import pbrt_amd as mi
 par = __import__("importlib").import_module("physics-based-ray-tracing_amd.parallel")
-sc = mi.load_file("tests/scenes/cbox.xml", res=512, spp=2048)
+sc = mi.load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/scenes/cbox.xml"), res=512, spp=2048)
 sc.device()
 ctx = mi.default_context()
 for r in (0, 3):

@@ -41,12 +41,13 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 }
 
 // waves per SIMD the register allocator aims for: the ultrasound bounce (GGX sampling, expf / sinf / acosf) needs
-// about 95 VGPRs and spills 110 bytes per lane at the radiance kernel's 8 waves (64 VGPRs) -- measured, the spilling
-// build is still the fastest (8 waves 2.83 ms, 6 waves 2.98, 4 waves 3.06 on Sphere_Box 5 x 64 x 65536)
+// about 95 VGPRs: 4 waves per SIMD run it without spills.  (While same-word global atomics dominated the kernel the
+// spilling 8-wave build was the fastest -- 2.83 / 2.98 / 3.06 ms at 8 / 6 / 4 waves; with the echoes summed in LDS
+// it is the other way round: 1.17 / 1.10 / 1.11 ms on Sphere_Box 5 x 64 x 65536.)
 #define US_AGG_LOG2 8
 #define US_AGG_BINS (1u << US_AGG_LOG2)
 #ifndef US_WAVES_PER_EU
-#define US_WAVES_PER_EU 8
+#define US_WAVES_PER_EU 4
 #endif
 __host__ __device__ constexpr uint32_t us_waves_per_eu(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? seg_waves_per_eu(accel) : US_WAVES_PER_EU;

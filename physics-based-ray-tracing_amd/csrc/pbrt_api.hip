@@ -749,7 +749,10 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     }
     for (uint32_t e = 0; e < NE; ++e)
         ex[e] = (float)((double)p->pitch * ((double)(float)e - ((double)NE - 1.0) / 2.0));  // :248
-    const uint64_t pass_paths = 8u << 20;
+#ifndef US_PASS_PATHS
+#define US_PASS_PATHS (16u << 20)  // paths in flight per pass; config 3 (268 M paths): 8 / 16 / 32 / 64 Mi -> 13.1 / 12.7 / 13.0 / 13.2 ms
+#endif
+    const uint64_t pass_paths = US_PASS_PATHS;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
     const uint32_t REGION = us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);

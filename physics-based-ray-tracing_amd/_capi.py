@@ -23,6 +23,7 @@ EMIT_AREA, EMIT_POINT = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
 FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 FILM_RAW_ACCUM = 1
+FILM_NO_REPACK = 2
 US_MAX_ANGLES = 64
 
 USQ_DIAG_SAMPLE = 0x1

@@ -578,7 +578,7 @@ class SamplingIntegrator(IntegratorBase):
     max_depth = 0xFFFFFFFF
     rr_depth = 5
 
-    def _film_desc(self, scene, sensor, seed, spp, crop=None, sample_offset=0, raw=False, pass_paths=0):
+    def _film_desc(self, scene, sensor, seed, spp, crop=None, sample_offset=0, raw=False, pass_paths=0, flags=0):
         film = sensor.film()
         fd = _capi.FilmDesc()
         cx, cy, cw, ch = crop if crop is not None else film.crop
@@ -589,17 +589,18 @@ class SamplingIntegrator(IntegratorBase):
         fd.rr_depth = int(self.rr_depth)
         fd.filter = film.rfilter.kind
         fd.seed = int(seed) & 0xFFFFFFFF
-        fd.flags = _capi.FILM_RAW_ACCUM if raw else 0
+        fd.flags = (_capi.FILM_RAW_ACCUM if raw else 0) | int(flags)
         fd.pass_paths = int(pass_paths)
         return fd
 
-    def render(self, scene, sensor=0, seed=0, spp=0, crop=None, sample_offset=0, raw=False, out_dev=None, pass_paths=0):
+    def render(self, scene, sensor=0, seed=0, spp=0, crop=None, sample_offset=0, raw=False, out_dev=None, pass_paths=0,
+               flags=0):
         """-> float32 [crop_h, crop_w, 3] (4 with raw=True).  With out_dev (a device pointer, e.g.
         tensor.data_ptr()) the film stays in HBM and None is returned."""
         sens = scene.sensors()[sensor] if isinstance(sensor, int) else sensor
         if not isinstance(sens, PerspectiveSensor):
             raise TypeError("radiance rendering needs a 'perspective' sensor")
-        fd = self._film_desc(scene, sens, seed, spp, crop, sample_offset, raw, pass_paths)
+        fd = self._film_desc(scene, sens, seed, spp, crop, sample_offset, raw, pass_paths, flags)
         cam = sens.camera()
         dev = scene.device()
         nch = 4 if raw else 3

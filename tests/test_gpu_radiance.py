@@ -204,3 +204,20 @@ def test_full_size_energy_sanity(cbox_full):
     assert 0.99 <= np.median(lum) <= 1.2
     assert img[:, :170].mean(axis=(0, 1)).argmax() == 1   # left third is dominated by the green wall
     assert img[:, 342:].mean(axis=(0, 1)).argmax() == 0   # right third by the red wall
+
+
+def test_bvh_scene_at_scale_queue_and_repack(mi, ob, capi):
+    """the ring scene with a few hundred regions: chunk queue, per-region slot reservation and the re-dealing of the
+    live paths before bounces >= 2 (k_scan_owners / k_repack_copy) change slot order only -- same film with and
+    without the repack, with other pass sizes, and equal to the oracle on a band"""
+    sc = mi.load_file(scene_path("testring.xml"), res=320, spp=12)
+    integ = sc.integrator()
+    img = integ.render(sc, seed=2, spp=12)
+    assert np.array_equal(img, integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_REPACK))
+    assert np.array_equal(img, integ.render(sc, seed=2, spp=12, pass_paths=300_000))      # 5 passes of 2-3 samples
+    assert np.array_equal(img, integ.render(sc, seed=2, spp=12))                           # slot order is not deterministic
+    band = (0, 150, 320, 24)
+    ref, _ = oracle_render(ob, sc, 2, 12, crop=band)
+    assert np.array_equal(img[150:174], ref) and img.mean() > 0
+    st = mi.default_context().stats()
+    assert st["samples"] == 320 * 320 * 12 and st["live"][0] == st["samples"] and st["live"][2] < st["live"][1] < st["live"][0]

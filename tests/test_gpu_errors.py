@@ -1,0 +1,75 @@
+"""Error behaviour of the C-ABI on a GPU box: invalid arguments come back as error codes (RuntimeError with the
+library's message in the Python layer), never as crashes or silent CPU fallbacks; degenerate-but-valid inputs work."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import scene_path
+
+pytestmark = pytest.mark.gpu
+
+
+def test_invalid_render_arguments_are_refused(mi, capi):
+    sc = mi.load_file(scene_path("cbox.xml"), res=16, spp=2)
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    dev = sc.device()
+    cam = sens.camera()
+    out = np.empty((16, 16, 3), np.float32)
+
+    def call(**kw):
+        fd = integ._film_desc(sc, sens, 0, 2)
+        for k, v in kw.items():
+            setattr(fd, k, v)
+        return dev.ctx.lib.pbrt_render_radiance(dev.handle, C.byref(cam), C.byref(fd), capi.addr(out))
+
+    assert call() == 0
+    for bad in (dict(crop_w=0), dict(crop_x=10, crop_w=10), dict(crop_y=16, crop_h=1), dict(spp=0), dict(max_depth=0), dict(filter=7)):
+        rc = call(**bad)
+        assert rc < 0, bad
+        assert len(dev.ctx.lib.pbrt_last_error(dev.ctx.handle)) > 0
+    assert dev.ctx.lib.pbrt_render_radiance(dev.handle, C.byref(cam), None, capi.addr(out)) < 0
+    assert dev.ctx.lib.pbrt_render_radiance(None, C.byref(cam), None, capi.addr(out)) < 0
+    assert call() == 0                                              # the context is still usable afterwards
+
+
+def test_degenerate_but_valid_inputs(mi, ob):
+    sc = mi.load_file(scene_path("cbox.xml"), res=16, spp=1)
+    integ = sc.integrator()
+    one = integ.render(sc, seed=3, spp=1, crop=(7, 9, 1, 1))         # 1 x 1 crop, 1 sample
+    assert one.shape == (1, 1, 3) and np.isfinite(one).all()
+    full = integ.render(sc, seed=3, spp=1)
+    assert np.array_equal(one[0, 0], full[9, 7])
+    # a scene whose camera sees nothing: every path misses at depth 0
+    empty = mi.load_dict({"type": "scene", "integrator": {"type": "path", "max_depth": 3},
+                          "sensor": {"type": "perspective", "to_world": mi.ScalarTransform4f().look_at([0, 0, 4], [0, 0, 5], [0, 1, 0]),
+                                     "film": {"type": "hdrfilm", "width": 8, "height": 8, "rfilter": {"type": "box"}},
+                                     "sampler": {"type": "independent", "sample_count": 2}},
+                          "s": {"type": "sphere", "center": [0, 0, 0], "radius": 1.0, "bsdf": {"type": "diffuse"}},
+                          "light": {"type": "point", "position": [0, 3, 0], "intensity": {"type": "rgb", "value": [1, 1, 1]}}})
+    img = mi.render(empty, seed=0)
+    assert img.shape == (8, 8, 3) and np.array_equal(img, np.zeros_like(img))
+    st = mi.default_context().stats()
+    assert st["segments"] == 0 and st["live"][0] == 128 and st["live"][1] == 0
+
+
+def test_invalid_ultrasound_and_leaf_arguments(mi, capi):
+    us = mi.load_file(scene_path("us_plate.xml"))
+    ui = us.integrator()
+    dev = us.device()
+    p = ui.us_params(us)
+    buf = np.empty((ui.n_angles, ui.n_elements, ui.time_samples), np.float32)
+    tx = np.empty(ui.n_angles * ui.n_elements, np.float32)
+    lib = dev.ctx.lib
+    assert lib.pbrt_us_acquire(dev.handle, C.byref(p), 0, 4, 0, 4, capi.addr(buf), capi.addr(tx)) == 0
+    p.n_angles = 0
+    assert lib.pbrt_us_acquire(dev.handle, C.byref(p), 0, 4, 0, 4, capi.addr(buf), capi.addr(tx)) < 0
+    p = ui.us_params(us)
+    assert lib.pbrt_us_acquire(dev.handle, C.byref(p), 0, 0, 0, 4, capi.addr(buf), capi.addr(tx)) <= 0   # zero paths: nothing to do or refused
+    assert lib.pbrt_us_acquire(dev.handle, None, 0, 4, 0, 4, capi.addr(buf), capi.addr(tx)) < 0
+    o = np.zeros((3, 4), np.float32)
+    assert lib.pbrt_ray_intersect(dev.handle, 4, capi.addr(o), None, None, None, None, None, None) < 0
+    with pytest.raises(RuntimeError):
+        mi.apply_pulse(np.zeros((2, 100), np.float32), 50e6, 3e6, -1.0)
+    with pytest.raises(RuntimeError):
+        mi.log_compress(np.ones(4, np.float32), dynamic_range=0.0)

@@ -33,6 +33,9 @@
 #ifndef REGION_SEGS_BVH
 #define REGION_SEGS_BVH 4
 #endif
+#ifndef REGION_SEGS_BRUTE
+#define REGION_SEGS_BRUTE 1
+#endif
 #ifndef REGION_SEGS_US
 #define REGION_SEGS_US 8
 #endif
@@ -47,7 +50,7 @@ __host__ __device__ constexpr uint32_t us_region_segs(int) { return REGION_SEGS_
 // ACCEL_K_BRUTE_BIG  uniform primitive loop, tables in global memory (brute force forced on a large scene)
 enum { ACCEL_K_BRUTE = 0, ACCEL_K_BVH_GLOBAL = 1, ACCEL_K_BVH_LDS = 2, ACCEL_K_BRUTE_BIG = 3 };
 __host__ __device__ constexpr uint32_t rad_region_segs(int accel) {
-    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? REGION_SEGS_BVH : 1;
+    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? REGION_SEGS_BVH : REGION_SEGS_BRUTE;
 }
 __host__ __device__ constexpr uint32_t seg_threads(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH : SEG_BRUTE;

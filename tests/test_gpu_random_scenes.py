@@ -1,0 +1,62 @@
+"""Randomised geometry: spheres, rectangles (parallelograms) and triangle meshes in random poses, small scenes (brute
+force) and large ones (BVH), random rays -- the closest hit, the occlusion test and a short render equal the oracle's
+bit for bit.  Seeds are fixed: the cases are reproducible."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_scene(mi, tmp_path, seed, n_spheres, n_rects, n_tris):
+    rng = np.random.default_rng(seed)
+    T = mi.ScalarTransform4f
+    d = {"type": "scene", "integrator": {"type": "path", "max_depth": 4},
+         "sensor": {"type": "perspective", "fov": 50, "to_world": T().look_at([0, 0, 6], [0, 0, 0], [0, 1, 0]),
+                    "film": {"type": "hdrfilm", "width": 24, "height": 20, "rfilter": {"type": "tent"}},
+                    "sampler": {"type": "independent", "sample_count": 3}},
+         "light": {"type": "rectangle", "to_world": T().translate([0, 2.9, 0]) @ T().rotate([1, 0, 0], 90) @ T().scale([1.5, 1.5, 1]),
+                   "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [3, 3, 3]}}, "bsdf": {"type": "diffuse"}},
+         "floor": {"type": "rectangle", "to_world": T().translate([0, -3, 0]) @ T().rotate([1, 0, 0], -90) @ T().scale([4, 4, 1]),
+                   "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.6, 0.6, 0.6]}}}}
+    mats = [{"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.7, 0.4, 0.3]}}, {"type": "conductor"}, {"type": "dielectric"}]
+    for i in range(n_spheres):
+        d[f"s{i}"] = {"type": "sphere", "center": list(rng.uniform(-2, 2, 3)), "radius": float(rng.uniform(0.2, 0.7)), "bsdf": mats[i % 3]}
+    for i in range(n_rects):
+        tw = T().translate(list(rng.uniform(-2, 2, 3))) @ T().rotate(list(rng.normal(size=3)), float(rng.uniform(0, 360))) @ \
+            T().scale([float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2)), 1])
+        d[f"r{i}"] = {"type": "rectangle", "to_world": tw, "bsdf": mats[0]}
+    if n_tris:
+        v = rng.uniform(-2.5, 2.5, (n_tris, 1, 3)) + rng.normal(scale=0.25, size=(n_tris, 3, 3))
+        path = tmp_path / f"soup{seed}.obj"
+        with open(path, "w") as f:
+            for p in v.reshape(-1, 3):
+                f.write(f"v {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}\n")
+            for i in range(n_tris):
+                f.write(f"f {3 * i + 1} {3 * i + 2} {3 * i + 3}\n")
+        d["soup"] = {"type": "obj", "filename": str(path), "bsdf": mats[0]}
+    return mi.load_dict(d)
+
+
+@pytest.mark.parametrize("seed,ns,nr,nt", [(1, 3, 4, 0), (2, 5, 10, 12), (3, 0, 2, 400), (4, 6, 6, 1500)])
+def test_random_scene_leaf_ops_and_render(mi, ob, capi, tmp_path, seed, ns, nr, nt):
+    sc = _random_scene(mi, tmp_path, seed, ns, nr, nt)
+    n_prims = len(sc.flatten()["prims"])
+    assert (n_prims <= 32) == (nt <= 12)                       # both accelerators are exercised across the cases
+    rng = np.random.default_rng(100 + seed)
+    n = 30000
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d[:50] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, 50)] * rng.choice([-1, 1], (50, 1)).astype(np.float32)   # axis-aligned rays
+    tmax = np.where(np.arange(n) % 4 == 0, 2.0, np.inf).astype(np.float32)
+    osc = ob.OracleScene.from_scene(sc)
+    got = sc.ray_intersect(o, d, tmax)
+    t, prim, u, v = osc.ray_intersect(o, d, tmax)
+    assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"], t)
+    assert np.array_equal(got["u"], u) and np.array_equal(got["v"], v)
+    assert np.array_equal(sc.ray_test(o, d, tmax), osc.ray_test(o, d, tmax))
+    assert 0.2 < got["valid"].mean() < 1.0
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    img = mi.render(sc, seed=seed)
+    ref = osc.render(sens.camera(), integ._film_desc(sc, sens, seed, 3), n_threads=8)
+    assert np.array_equal(img, ref) and img.mean() > 0

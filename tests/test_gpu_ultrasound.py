@@ -112,3 +112,34 @@ def test_config3_scale_properties(mi):
     assert ea > 0 and abs(ea - eb) / ea < 0.05
     again = ui._acquire(sc, ui.quirks, paths_per_ray=P, path_offset=0, seed=0)
     assert np.array_equal(again != 0, a != 0) and rel_l2(again, a) <= 1e-5
+
+
+@pytest.mark.parametrize("seed,n_spheres,n_plates,quirks", [(1, 1, 2, None), (2, 3, 4, 0), (3, 2, 40, None)])
+def test_random_phantoms_match_oracle(mi, ob, capi, seed, n_spheres, n_plates, quirks):
+    """random phantoms in front of the probe: a few shapes (brute force) and many plates (BVH), the reference's literal
+    arithmetic (default quirks) and the intent arithmetic (quirks = 0)"""
+    rng = np.random.default_rng(seed)
+    T = mi.ScalarTransform4f
+    d = {"type": "scene",
+         "integrator": {"type": "ultrasound_integrator", "max_depth": 6, "sampling_rate": 40e6, "frequency": 4e6, "sound_speed": 1500,
+                        "attenuation": 0.3, "main_beam_angle": 20, "cutoff_angle": 35, "n_elements": 32, "pitch": 2e-4,
+                        "time_samples": 4000, "angles": [-10.0, 0.0, 10.0], "paths_per_ray": 60, "seed": seed,
+                        **({} if quirks is None else {"quirks": quirks})},
+         "sensor": {"type": "ultrasound_sensor", "to_world": T().look_at([0, 0, 0], [0, 0, 0.03], [0, 1, 0])}}
+    for i in range(n_spheres):
+        d[f"s{i}"] = {"type": "sphere", "center": [float(rng.uniform(-0.01, 0.01)), float(rng.uniform(-0.005, 0.005)), float(rng.uniform(0.02, 0.05))],
+                      "radius": float(rng.uniform(0.003, 0.008)),
+                      "bsdf": {"type": "ultrasound_bsdf", "impedance": float(rng.uniform(2, 8)), "roughness": float(rng.uniform(0.2, 0.9))}}
+    for i in range(n_plates):
+        tw = T().translate([float(rng.uniform(-0.012, 0.012)), float(rng.uniform(-0.004, 0.004)), float(rng.uniform(0.015, 0.06))]) @ \
+            T().rotate([0, 1, 0], float(rng.uniform(-40, 40))) @ T().rotate([1, 0, 0], float(rng.uniform(150, 210))) @ \
+            T().scale([float(rng.uniform(0.002, 0.01)), float(rng.uniform(0.004, 0.01)), 1])
+        d[f"p{i}"] = {"type": "rectangle", "to_world": tw,
+                      "bsdf": {"type": "ultrasound_bsdf", "impedance": float(rng.uniform(2, 8)), "roughness": float(rng.uniform(0.2, 0.9))}}
+    sc = mi.load_dict(d)
+    assert (len(sc.flatten()["prims"]) > 32) == (n_plates > 30)
+    ui = sc.integrator()
+    ui.simulate_acquisition_parallel(sc)
+    ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), seed, 60)
+    check(ui.channel_buf, ref)
+    assert (ref != 0).sum() > 50

@@ -60,3 +60,40 @@ def test_random_scene_leaf_ops_and_render(mi, ob, capi, tmp_path, seed, ns, nr, 
     img = mi.render(sc, seed=seed)
     ref = osc.render(sens.camera(), integ._film_desc(sc, sens, seed, 3), n_threads=8)
     assert np.array_equal(img, ref) and img.mean() > 0
+
+
+def test_mesh_larger_than_lds_takes_the_global_bvh_kernels(mi, ob, capi, tmp_path):
+    """a 20 000-triangle sphere mesh (2.5 MB of nodes + primitives: no LDS image): k_bounce / k_us_bounce traverse the
+    BVH through the vector caches (ACCEL_K_BVH_GLOBAL) -- same contract, bit-exact against the oracle"""
+    nu, nv = 100, 100
+    th = np.linspace(0, np.pi, nv + 1)[:, None]
+    ph = np.linspace(0, 2 * np.pi, nu, endpoint=False)[None, :]
+    P = np.stack([np.sin(th) * np.cos(ph), np.cos(th) * np.ones_like(ph), np.sin(th) * np.sin(ph)], axis=-1)     # [nv+1, nu, 3]
+    idx = lambda i, j: i * nu + (j % nu) + 1
+    path = tmp_path / "ball.obj"
+    with open(path, "w") as f:
+        for p in P.reshape(-1, 3):
+            f.write(f"v {p[0]:.6f} {p[1]:.6f} {p[2]:.6f}\n")
+        for i in range(nv):
+            for j in range(nu):
+                f.write(f"f {idx(i, j)} {idx(i + 1, j + 1)} {idx(i + 1, j)}\n")
+                f.write(f"f {idx(i, j)} {idx(i, j + 1)} {idx(i + 1, j + 1)}\n")
+    T = mi.ScalarTransform4f
+    sc = mi.load_dict({
+        "type": "scene", "integrator": {"type": "path", "max_depth": 4},
+        "sensor": {"type": "perspective", "fov": 45, "to_world": T().look_at([0, 1, 5], [0, 0, 0], [0, 1, 0]),
+                   "film": {"type": "hdrfilm", "width": 40, "height": 32, "rfilter": {"type": "tent"}},
+                   "sampler": {"type": "independent", "sample_count": 4}},
+        "ball": {"type": "obj", "filename": str(path), "merge_quads": False,
+                 "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.7, 0.5, 0.4]}}},
+        "floor": {"type": "rectangle", "to_world": T().translate([0, -1.2, 0]) @ T().rotate([1, 0, 0], -90) @ T().scale([5, 5, 1]),
+                  "bsdf": {"type": "diffuse"}},
+        "light": {"type": "rectangle", "to_world": T().translate([0, 4, 0]) @ T().rotate([1, 0, 0], 90) @ T().scale([1, 1, 1]),
+                  "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [10, 10, 10]}}, "bsdf": {"type": "diffuse"}}})
+    assert len(sc.flatten()["prims"]) == 20002
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    img = mi.render(sc, seed=9)
+    ref = ob.OracleScene.from_scene(sc).render(sens.camera(), integ._film_desc(sc, sens, 9, 4), n_threads=8)
+    assert np.array_equal(img, ref) and img.mean() > 0.01
+    big = integ.render(sc, seed=9, spp=4, pass_paths=3000)            # several passes, repack between bounces
+    assert np.array_equal(big, img)

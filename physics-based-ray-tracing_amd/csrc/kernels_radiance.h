@@ -1,21 +1,23 @@
 // kernels_radiance.h -- radiance-mode wavefront kernels (gfx950).
 //
-// Layout in HBM (DESIGN.md "Data layout"): path state is a structure of arrays, 15 dwords per slot
+// Layout in HBM (DESIGN.md "Data layout"): path state is a tiled structure of arrays (state_voff below), 15 dwords
+// per slot
 //   [0..2] ray origin  [3..5] ray direction  [6..8] throughput rgb  [9..11] radiance rgb
 //   [12] eta  [13] pdf of the previous BSDF sample (< 0: previous event was a delta lobe / camera)
 //   [14] home slot (uint32): index of the path's radiance accumulator and of its pixel/sample
 // Slots are grouped in segments of SEG = workgroup size.  One bounce = one launch: workgroup g reads
-// the live prefix of segment g of the `in` state, advances every path by one bounce (closest hit,
+// the live prefix of region g of the `in` state, advances every path by one bounce (closest hit,
 // emission + MIS, next-event estimation with its shadow ray, BSDF sample, Russian roulette) and
-// writes the survivors, compacted to the front of segment g of the `out` state with a wave ballot
-// + mbcnt prefix and an 16-entry LDS scan across the workgroup's waves.  No global atomics are on
+// writes the survivors, compacted to the front of region g of the `out` state: brute-force scenes with a wave
+// ballot + mbcnt prefix and a scan across the workgroup's waves through LDS (region = one segment), BVH scenes with
+// a chunk queue and a slot reservation in LDS (region = REGION_SEGS_BVH segments).  No global atomics are on
 // the path-state data path; paths that end write their radiance once to Lhome[home].
 #pragma once
 #include "device_scene.h"
 
 // slots per compaction segment == threads per workgroup (seg_threads(ACCEL) below).  Measured on MI355X, cbox
-// 512^2 x 256 spp: 1024 -> 10.8 ms, 512 -> 10.3 ms, 256 -> 10.2 ms; the LDS-staged BVH wants the largest
-// workgroup (ring: 39 ms at 1024, 78 ms at 256).
+// 512^2 x 256 spp (current kernel): 128 / 256 / 512 / 1024 -> 10.5 / 9.0 / 8.6 / 9.9 ms; the LDS-staged BVH wants
+// the largest workgroup (ring: 39 ms at 1024, 78 ms at 256 when first measured).
 #ifndef SEG_BRUTE
 #define SEG_BRUTE 512
 #endif
@@ -25,11 +27,11 @@
 #ifndef SEG_WAVES_PER_EU
 #define SEG_WAVES_PER_EU 8  // __launch_bounds__ hint for the brute-force kernels: 64 VGPRs, 8 waves per SIMD
 #endif
-// A workgroup owns a REGION of region_segs * SEG slots and walks its live prefix SEG paths at a time.
-// Measured on MI355X (DESIGN.md "Tuning"): walking several chunks amortises the LDS staging of BVH scenes
-// (ring: 47 -> 39 ms) and the block prologue of the ultrasound kernel (3.9 -> 3.1 ms), but the per-chunk
-// barrier puts the 16 waves of a brute-force radiance workgroup in lock-step (cbox: 12.3 -> 15.6 ms), so
-// that variant keeps one chunk per workgroup.
+// A workgroup owns a REGION of region_segs * SEG slots and walks its live prefix in chunks.
+// Measured on MI355X: walking several chunks amortises the LDS staging of BVH scenes
+// (ring: 47 -> 39 ms; best at 4 segments with the chunk queue) and the block prologue of the ultrasound kernel
+// (3.9 -> 3.1 ms), but any loop around the bounce body pushes the brute-force radiance kernel over its 64-VGPR
+// budget (2 / 4 segments: 13.6 / 12.0 ms against 8.2), so that variant keeps one chunk per workgroup.
 #ifndef REGION_SEGS_BVH
 #define REGION_SEGS_BVH 4
 #endif

@@ -5,8 +5,8 @@
 // radiance mode; state is 11 dwords per slot:
 //   [0..2] origin [3..5] direction [6] amp [7] atten [8] tof [9] geo_len [10] home (uint32)
 // home = ray_id * paths_this_pass + k_local, ray_id = angle * n_elements + element.
-// Echoes are scattered into channel_buf[(angle * n_elements + recv) * T + t_idx] with one f32
-// global atomic per visible bounce (CustomIntegrator.py:351-354).
+// Echoes go to channel_buf[(angle * n_elements + recv) * T + t_idx] (CustomIntegrator.py:351-354): summed per
+// workgroup in a small LDS table keyed by that index, then one f32 global atomic per used bin.
 #pragma once
 #include "kernels_radiance.h"
 

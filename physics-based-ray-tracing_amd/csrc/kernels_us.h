@@ -30,6 +30,12 @@ struct UsArgs {
     uint32_t ppr_pass, path_first;  // paths per ray in this pass, global index of local path 0
     uint32_t lds_bytes;
     uint32_t stat_stride;
+    // First-bounce tables (k_us_first): the primary ray of an (angle, element) pair is deterministic
+    // (CustomIntegrator.py:270-273), so all P paths of a ray share the first hit, and the occlusion of the ray to a
+    // receive element depends on (ray, element) only.  Computed once per acquisition with the same arithmetic; the first
+    // bounce of every path looks them up instead of walking the scene twice.  Null: walk the scene (same result).
+    const float4 *first_hit;   // [n_rays]: t, u, v, slot as bits (0xffffffff: miss)
+    const uint8_t *first_vis;  // [n_rays][n_elements]: 1 = receive element visible from the first hit
 };
 
 DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // CustomIntegrator.py:289-304
@@ -145,7 +151,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         const uint32_t depth = a.depth;
         const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         Hit h;
-        if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h)) {                 // :309-312
+        bool hit;
+        if (FIRST && a.first_hit) {  // shared first hit of the ray (k_us_first)
+            const float4 r = a.first_hit[ray_id];
+            h.t = r.x;
+            h.u = r.y;
+            h.v = r.z;
+            h.slot = __float_as_uint(r.w);
+            h.prim = 0;
+            hit = h.slot != 0xffffffffu;
+        } else {
+            hit = scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h);             // :309-312
+        }
+        if (hit) {
             did_seg = true;
             const pbrt_prim &P = tb.prims_by_slot[h.slot];
             SI si = make_si(P, o, d, h.t, h.u, h.v);
@@ -160,8 +178,12 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             float dist_recv = sqrtf(dot(tv, tv));
             V3 sec_dir = tv * (1.0f / dist_recv);                                      // :322
             Hit hs;
-            bool visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF,
-                                                         &hs);                          // :324-325
+            bool visible;
+            if (FIRST && a.first_vis)
+                visible = a.first_vis[(size_t)ray_id * NE + recv] != 0;
+            else
+                visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF,
+                                                        &hs);                           // :324-325
             atten *= expf(a.katt * distance / 8.686f);                                 // :328
             float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
             float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;           // :329
@@ -268,6 +290,41 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         row[stride] += ns_acc;  // one occlusion ray per shaded segment
         row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
     }
+}
+
+// First-bounce tables, one thread per (ray, receive element): the primary ray, its closest hit, and the occlusion test
+// towards the element -- the statements of k_us_bounce<FIRST> up to `visible`, once instead of once per path.
+// ACCEL: ACCEL_K_BRUTE_BIG or ACCEL_K_BVH_GLOBAL (no LDS image needed for n_rays * n_elements rays; same primitive
+// order / same tree, so the same hit).
+template <int ACCEL>
+__global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_rays, float4 *first_hit, uint8_t *first_vis) {
+    const uint32_t NE = a.p.n_elements;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rays * NE) return;
+    const uint32_t ray_id = i / NE, recv = i - ray_id * NE;
+    const uint32_t ang = ray_id / NE, el = ray_id - ang * NE;
+    const V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));            // :270,273
+    const V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);          // :271,273
+    LdsScene ls = {nullptr, nullptr, nullptr};
+    Hit h;
+    const bool hit = scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h);
+    if (recv == 0) {
+        float4 r = {0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu)};
+        if (hit) r = {h.t, h.u, h.v, __uint_as_float(h.slot)};
+        first_hit[ray_id] = r;
+    }
+    uint8_t vis = 0;
+    if (hit) {
+        const pbrt_prim &P = a.sc.prims[h.slot];
+        SI si = make_si(P, o, d, h.t, h.u, h.v);
+        V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f));       // :320-321
+        V3 tv = target - si.p;
+        float dist_recv = sqrtf(dot(tv, tv));
+        V3 sec_dir = tv * (1.0f / dist_recv);                                            // :322
+        Hit hs;
+        vis = scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF, &hs) ? 0 : 1;
+    }
+    first_vis[i] = vis;
 }
 
 __global__ __launch_bounds__(256) void k_scale(float *buf, size_t n, float s) {

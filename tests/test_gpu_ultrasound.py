@@ -143,3 +143,15 @@ def test_random_phantoms_match_oracle(mi, ob, capi, seed, n_spheres, n_plates, q
     ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), seed, 60)
     check(ui.channel_buf, ref)
     assert (ref != 0).sum() > 50
+
+
+@pytest.mark.parametrize("scene", ["us_sphere_box.xml", "us_cone_box.xml"])
+def test_first_bounce_tables_change_nothing(mi, capi, scene):
+    """the shared first hit / visibility tables (k_us_first) against every path walking the scene itself: the same
+    arithmetic, so the same channel buffer up to the order of the float additions"""
+    sc = mi.load_file(scene_path(scene), paths_per_ray=128, seed=8)
+    ui = sc.integrator()
+    with_tables = ui._acquire(sc, ui.quirks)
+    without = ui._acquire(sc, ui.quirks | capi.USQ_NO_FIRST_TABLES)
+    assert np.array_equal(with_tables != 0, without != 0) and (with_tables != 0).sum() > 100
+    assert np.allclose(with_tables, without, rtol=2e-5, atol=1e-7 * np.abs(without).max())

@@ -32,10 +32,12 @@ struct UsArgs {
     uint32_t stat_stride;
     // First-bounce tables (k_us_first): the primary ray of an (angle, element) pair is deterministic
     // (CustomIntegrator.py:270-273), so all P paths of a ray share the first hit, and the occlusion of the ray to a
-    // receive element depends on (ray, element) only.  Computed once per acquisition with the same arithmetic; the first
-    // bounce of every path looks them up instead of walking the scene twice.  Null: walk the scene (same result).
-    const float4 *first_hit;   // [n_rays]: t, u, v, slot as bits (0xffffffff: miss)
-    const uint8_t *first_vis;  // [n_rays][n_elements]: 1 = receive element visible from the first hit
+    // receive element, the directivity weight, the echo time and its carrier depend on (ray, element) only.  Computed
+    // once per acquisition with the same statements; the first bounce of every path looks them up instead of walking
+    // the scene twice and evaluating sqrtf / acosf / sinf / rintf.  Null: every path computes them (same result).
+    const float4 *first_hit;  // [n_rays]: t, u, v, slot as bits (0xffffffff: miss)
+    const float4 *first_rx;   // [n_rays][n_elements]: fd = directivity * w_o, carrier (sin(phase) or 1), channel index as
+                              // bits (0xffffffff: occluded or outside the time window), unused
 };
 
 DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // CustomIntegrator.py:289-304
@@ -173,21 +175,26 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (!no_acc) tof += distance * a.inv_c;                                    // :316
             F4 u = rng4(ray_id, k, depth, a.seed);
             uint32_t recv = min((uint32_t)(u.x * (float)NE), NE - 1);                  // :319
-            V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f)); // :320-321
-            V3 tv = target - si.p;
-            float dist_recv = sqrtf(dot(tv, tv));
-            V3 sec_dir = tv * (1.0f / dist_recv);                                      // :322
-            Hit hs;
-            bool visible;
-            if (FIRST && a.first_vis)
-                visible = a.first_vis[(size_t)ray_id * NE + recv] != 0;
-            else
+            const bool tab = FIRST && a.first_rx != nullptr;  // (ray, receive element) record of k_us_first
+            float4 rx = {0.0f, 0.0f, 0.0f, 0.0f};
+            V3 sec_dir = {0.0f, 0.0f, 0.0f};
+            bool visible = false;
+            float total_time = 0.0f, phase = 0.0f;
+            if (tab) {
+                rx = a.first_rx[(size_t)ray_id * NE + recv];
+            } else {
+                V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f)); // :320-321
+                V3 tv = target - si.p;
+                float dist_recv = sqrtf(dot(tv, tv));
+                sec_dir = tv * (1.0f / dist_recv);                                     // :322
+                Hit hs;
                 visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF,
                                                         &hs);                           // :324-325
+                float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
+                total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;             // :329
+                phase = a.two_pi_f * total_time;                                       // :330
+            }
             atten *= expf(a.katt * distance / 8.686f);                                 // :328
-            float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
-            float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;           // :329
-            float phase = a.two_pi_f * total_time;                                     // :330
             const pbrt_material M = tb.mats[P.material];
             Frame fr = make_frame(si.n);
             V3 wi = to_local(fr, -d);
@@ -209,14 +216,24 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (ok) {
                 float cos_theta = dot(si.n, -d);                                       // :340
                 amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                        // :341
-                float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);                 // :286-287,345
-                float fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;        // :345
-                // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
-                float pressure = atten * amp * fd * ((a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase));  // :348
-                float tf = rintf(total_time * a.p.fs);                                 // :351-352
-                if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
-                if (tf >= 0.0f && tf < (float)T && visible) {                          // :353
-                    const uint32_t ci = (ang * NE + recv) * T + (uint32_t)tf;          // :354 (host checks it fits 32 bits)
+                float fd, carrier;
+                uint32_t ci = 0xffffffffu;
+                if (tab) {
+                    fd = rx.x;
+                    carrier = rx.y;
+                    ci = __float_as_uint(rx.z);
+                } else {
+                    float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);             // :286-287,345
+                    fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;          // :345
+                    // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
+                    carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
+                    float tf = rintf(total_time * a.p.fs);                             // :351-352
+                    if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
+                    if (tf >= 0.0f && tf < (float)T && visible)                        // :353
+                        ci = (ang * NE + recv) * T + (uint32_t)tf;                     // :354 (host checks it fits 32 bits)
+                }
+                float pressure = atten * amp * fd * carrier;                           // :348
+                if (ci != 0xffffffffu) {
 #ifdef PBRT_ABLATE_US_AGG  // diagnostic builds only
                     atomicAdd(&a.channel[ci], pressure);
 #else
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
 // ACCEL: ACCEL_K_BRUTE_BIG or ACCEL_K_BVH_GLOBAL (no LDS image needed for n_rays * n_elements rays; same primitive
 // order / same tree, so the same hit).
 template <int ACCEL>
-__global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_rays, float4 *first_hit, uint8_t *first_vis) {
+__global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_rays, float4 *first_hit, float4 *first_rx) {
     const uint32_t NE = a.p.n_elements;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rays * NE) return;
@@ -313,18 +330,33 @@ __global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_ray
         if (hit) r = {h.t, h.u, h.v, __uint_as_float(h.slot)};
         first_hit[ray_id] = r;
     }
-    uint8_t vis = 0;
+    float4 rx = {0.0f, 0.0f, __uint_as_float(0xffffffffu), 0.0f};
     if (hit) {
+        const uint32_t T = a.p.time_samples;
+        const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         const pbrt_prim &P = a.sc.prims[h.slot];
         SI si = make_si(P, o, d, h.t, h.u, h.v);
+        const float distance = h.t;                                                      // :314
+        const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
+        float tof = 0.0f;                                                                // :278
+        if (!no_acc) tof += distance * a.inv_c;                                          // :316
         V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f));       // :320-321
         V3 tv = target - si.p;
         float dist_recv = sqrtf(dot(tv, tv));
         V3 sec_dir = tv * (1.0f / dist_recv);                                            // :322
         Hit hs;
-        vis = scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF, &hs) ? 0 : 1;
+        const bool visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF, &hs);
+        float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
+        float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;                 // :329
+        float phase = a.two_pi_f * total_time;                                           // :330
+        float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);                           // :286-287,345
+        rx.x = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;                      // :345
+        rx.y = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
+        float tf = rintf(total_time * a.p.fs);                                           // :351-352
+        if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
+        if (tf >= 0.0f && tf < (float)T && visible) rx.z = __uint_as_float((ang * NE + recv) * T + (uint32_t)tf);  // :353-354
     }
-    first_vis[i] = vis;
+    first_rx[i] = rx;
 }
 
 __global__ __launch_bounds__(256) void k_scale(float *buf, size_t n, float s) {

@@ -805,7 +805,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     // first-bounce tables (kernels_us.h k_us_first): worth it once a ray has more paths than receive elements
     if (ppr >= NE && !(p->quirks & PBRT_USQ_NO_FIRST_TABLES)) {
         float4 *fh = (float4 *)c->buf("us_first_hit", (size_t)n_rays * 16);
-        uint8_t *fv = (uint8_t *)c->buf("us_first_vis", (size_t)n_rays * NE);
+        float4 *fv = (float4 *)c->buf("us_first_rx", (size_t)n_rays * NE * 16);
         if (!fh || !fv) return PBRT_E_NOMEM;
         const dim3 g(div_up((uint64_t)n_rays * NE, 256)), b(256);
         if (s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG)
@@ -814,7 +814,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
             hipLaunchKernelGGL(k_us_first<ACCEL_K_BVH_GLOBAL>, g, b, 0, st, a, n_rays, fh, fv);
         HIPCHK(c, hipGetLastError());
         a.first_hit = fh;
-        a.first_vis = fv;
+        a.first_rx = fv;
     }
     size_t n_ev = 0;
     hipEvent_t pass_e1 = nullptr;

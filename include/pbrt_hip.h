@@ -43,7 +43,9 @@ extern "C" {
  *   SPHERE         g = centre[3], radius, 8 x 0
  *   PARALLELOGRAM  g = corner[3], e1[3], e2[3], n[3]   (Mitsuba 'rectangle' under to_world:
  *                  corner = T(-1,-1,0), e1 = T(1,-1,0)-corner, e2 = T(-1,1,0)-corner)
- *   CONE           g = base centre[3], axis (base->apex, length = height)[3], base radius, 5 x 0
+ *   CONE           g = row-major 3x4 world -> object matrix of the closed unit cone (apex (0,0,1), base disc of
+ *                  radius 1 in z = 0): any affine to_world, e.g. the 0.06 / 0.06 / 0.10 scale of
+ *                  MitsubaScenes/Cone_Box.xml:36-47.  Hits report u = 0 (lateral surface) / 1 (base disc), v = 0.
  * The scenes that feed these: scenes/cbox.xml (12 triangles + 2 spheres), scenes/simple.xml
  * (teapot.ply, 2256 triangles), MitsubaScenes/ *.xml (sphere / rectangle / cone),
  * TestRing/TestRing.obj (1152 triangles).
@@ -51,7 +53,7 @@ extern "C" {
 #define PBRT_PRIM_TRIANGLE 0u
 #define PBRT_PRIM_SPHERE 1u
 #define PBRT_PRIM_PARALLELOGRAM 2u
-/* ('cone' shapes are tessellated into triangles by the host layer; there is no analytic cone primitive.) */
+#define PBRT_PRIM_CONE 3u /* analytic; cannot carry an area emitter (like SPHERE) */
 
 typedef struct pbrt_prim {
     float g[12];

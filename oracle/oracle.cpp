@@ -53,6 +53,46 @@ struct Scene {
 
 inline V3 g3(const pbrt_prim &P, int i) { return {P.g[i], P.g[i + 1], P.g[i + 2]}; }
 
+// Analytic cone ([DEFINE] D8: 'cone' of MitsubaScenes/Cone_Box.xml:36-47 = closed unit cone under to_world): the ray in
+// object space (world -> object matrix in g, t preserved) against x^2 + y^2 = (1 - z)^2, 0 <= z <= 1, and the base disc.
+// flag 0: lateral surface, 1: base disc.
+inline bool cone_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *flag) {
+    const V3 r0 = g3(P, 0), r1 = g3(P, 4), r2 = g3(P, 8);
+    const V3 oo = {dot(r0, o) + P.g[3], dot(r1, o) + P.g[7], dot(r2, o) + P.g[11]};
+    const V3 dd = {dot(r0, d), dot(r1, d), dot(r2, d)};
+    const float ow = 1.0f - oo.z;
+    const float A = fmaf(dd.x, dd.x, fmaf(dd.y, dd.y, -(dd.z * dd.z)));
+    const float b = fmaf(oo.x, dd.x, fmaf(oo.y, dd.y, ow * dd.z));
+    const float C = fmaf(oo.x, oo.x, fmaf(oo.y, oo.y, -(ow * ow)));
+    const float disc = fmaf(b, b, -(A * C));
+    float best = tmax;
+    float fl = 0.0f;
+    bool found = false;
+    if (disc >= 0.0f) {
+        const float q = -(b + copysignf(sqrtf(disc), b));
+        const float ta = q / A, tb = C / q;
+        const float za = fmaf(ta, dd.z, oo.z), zb = fmaf(tb, dd.z, oo.z);
+        if (ta >= 0.0f && ta <= best && za >= 0.0f && za <= 1.0f) {
+            best = ta;
+            found = true;
+        }
+        if (tb >= 0.0f && tb <= best && zb >= 0.0f && zb <= 1.0f && (!found || tb < best)) {
+            best = tb;
+            found = true;
+        }
+    }
+    const float tc = -oo.z / dd.z;
+    const float x = fmaf(tc, dd.x, oo.x), y = fmaf(tc, dd.y, oo.y);
+    if (tc >= 0.0f && tc <= best && fmaf(x, x, y * y) <= 1.0f && (!found || tc < best)) {
+        best = tc;
+        fl = 1.0f;
+        found = true;
+    }
+    *t = best;
+    *flag = fl;
+    return found;
+}
+
 // Closest-hit candidate test for one primitive.  Mitsuba: Mesh::ray_intersect_triangle,
 // Sphere::ray_intersect_preliminary, Rectangle::ray_intersect_preliminary (all reached through
 // scene.ray_intersect, CustomIntegrator.py:309).  Triangles and parallelograms share the
@@ -106,7 +146,11 @@ inline bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float
         *v = vs * inv;
         return true;
     }
-    return false;  // unknown primitive type (cones arrive as triangles)
+    if (P.type == PBRT_PRIM_CONE) {
+        *v = 0.0f;
+        return cone_hit(P, o, d, tmax, t, u);
+    }
+    return false;  // unknown primitive type
 }
 
 // Brute-force scenes (<= 32 primitives, walked in index order by every ray): candidate hit as the
@@ -114,12 +158,12 @@ inline bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float
 // test is ts <= tmax * det, candidates are ranked by cross-multiplication (closest_hit below) and
 // the one division happens after the loop.  Spheres report (t, 1).  DESIGN.md "Intersection".
 inline bool prim_candidate(const pbrt_prim &P, V3 o, V3 d, float tmax, float *num, float *den, float *us_, float *vs_) {
-    if (P.type == PBRT_PRIM_SPHERE) {
+    if (P.type == PBRT_PRIM_SPHERE || P.type == PBRT_PRIM_CONE) {
         float t, u, v;
         if (!prim_hit(P, o, d, tmax, &t, &u, &v)) return false;
         *num = t;
         *den = 1.0f;
-        *us_ = 0.0f;
+        *us_ = u;  // 0 for spheres; cone: lateral / base flag
         *vs_ = 0.0f;
         return true;
     }
@@ -263,6 +307,40 @@ bool any_hit_segment(const Scene &sc, V3 o, V3 d, float tmax) {
     return false;
 }
 
+// CONE primitives keep the world -> object matrix only; bounds and hull tests need the world-space base ellipse
+// (centre c, conjugate radii a, b) and the apex: solve M x = e - t by Cramer's rule in f64.
+static bool cone_frame(const pbrt_prim &P, double c[3], double a[3], double b[3], double apex[3]) {
+    const double M[3][3] = {{P.g[0], P.g[1], P.g[2]}, {P.g[4], P.g[5], P.g[6]}, {P.g[8], P.g[9], P.g[10]}};
+    auto det3 = [](const double m[3][3]) {
+        return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+               m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    };
+    const double D = det3(M);
+    if (!std::isfinite(D) || D == 0.0) return false;
+    auto solve = [&](const double rhs[3], double x[3]) {
+        for (int k = 0; k < 3; ++k) {
+            double m[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) m[i][j] = (j == k) ? rhs[i] : M[i][j];
+            x[k] = det3(m) / D;
+        }
+    };
+    const double t[3] = {P.g[3], P.g[7], P.g[11]};
+    const double r0[3] = {-t[0], -t[1], -t[2]}, rx[3] = {1 - t[0], -t[1], -t[2]}, ry[3] = {-t[0], 1 - t[1], -t[2]},
+                 rz[3] = {-t[0], -t[1], 1 - t[2]};
+    double px[3], py[3];
+    solve(r0, c);
+    solve(rx, px);
+    solve(ry, py);
+    solve(rz, apex);
+    for (int k = 0; k < 3; ++k) {
+        a[k] = px[k] - c[k];
+        b[k] = py[k] - c[k];
+        if (!std::isfinite(c[k]) || !std::isfinite(a[k]) || !std::isfinite(b[k]) || !std::isfinite(apex[k])) return false;
+    }
+    return true;
+}
+
 void find_occluders(Scene &sc) {
     sc.occ.clear();
     for (size_t i = 0; i < sc.prims.size(); ++i) {
@@ -283,6 +361,15 @@ void find_occluders(Scene &sc) {
                     double s = side(Q.g[0], Q.g[1], Q.g[2]);
                     acc(s - (double)Q.g[3]);
                     acc(s + (double)Q.g[3]);
+                } else if (Q.type == PBRT_PRIM_CONE) {
+                    double cc[3], ca[3], cb[3], cx[3];
+                    cone_frame(Q, cc, ca, cb, cx);
+                    const double s = side(cc[0], cc[1], cc[2]);
+                    const double an = n[0] * ca[0] + n[1] * ca[1] + n[2] * ca[2], bn = n[0] * cb[0] + n[1] * cb[1] + n[2] * cb[2];
+                    const double r = std::sqrt(an * an + bn * bn) * (1.0 + 1e-12);
+                    acc(s - r);
+                    acc(s + r);
+                    acc(side(cx[0], cx[1], cx[2]));
                 } else {
                     const double v0[3] = {Q.g[0], Q.g[1], Q.g[2]}, e1[3] = {Q.g[3], Q.g[4], Q.g[5]}, e2[3] = {Q.g[6], Q.g[7], Q.g[8]};
                     acc(side(v0[0], v0[1], v0[2]));
@@ -310,6 +397,16 @@ void prim_bounds(const pbrt_prim &P, float lo[3], float hi[3]) {
         for (int k = 0; k < 3; ++k) {
             lo[k] = P.g[k] - P.g[3];
             hi[k] = P.g[k] + P.g[3];
+        }
+        return;
+    }
+    if (P.type == PBRT_PRIM_CONE) {
+        double cc[3], ca[3], cb[3], cx[3];
+        cone_frame(P, cc, ca, cb, cx);
+        for (int k = 0; k < 3; ++k) {
+            const double r = std::sqrt(ca[k] * ca[k] + cb[k] * cb[k]);
+            lo[k] = std::nextafter((float)std::min(cc[k] - r, cx[k]), -kInf);
+            hi[k] = std::nextafter((float)std::max(cc[k] + r, cx[k]), kInf);
         }
         return;
     }
@@ -392,6 +489,16 @@ inline SI make_si(const Scene &sc, V3 o, V3 d, const Hit &h) {
         V3 p = madd(d, h.t, o);
         si.n = normalize(p - c);
         si.p = madd(si.n, P.g[3], c);
+    } else if (P.type == PBRT_PRIM_CONE) {
+        const V3 r0 = g3(P, 0), r1 = g3(P, 4), r2 = g3(P, 8);
+        si.p = madd(d, h.t, o);
+        V3 no = {0.0f, 0.0f, -1.0f};
+        if (h.u == 0.0f) {
+            no = {dot(r0, si.p) + P.g[3], dot(r1, si.p) + P.g[7], 1.0f - (dot(r2, si.p) + P.g[11])};
+            if (!(dot(no, no) > 0.0f)) no = {0.0f, 0.0f, 1.0f};
+        }
+        si.n = normalize(V3{fmaf(r0.x, no.x, fmaf(r1.x, no.y, r2.x * no.z)), fmaf(r0.y, no.x, fmaf(r1.y, no.y, r2.y * no.z)),
+                            fmaf(r0.z, no.x, fmaf(r1.z, no.y, r2.z * no.z))});
     } else {
         si.p = madd(g3(P, 6), h.v, madd(g3(P, 3), h.u, g3(P, 0)));
         si.n = g3(P, 9);
@@ -821,10 +928,12 @@ int oracle_scene_create(const pbrt_scene_desc *desc, oracle_scene **out) {
     s->sc.light_prims.assign(desc->light_prims, desc->light_prims + desc->n_light_prims);
     s->sc.light_cdf.assign(desc->light_cdf, desc->light_cdf + desc->n_light_prims);
     for (auto &p : s->sc.prims) {
-        if (p.type > PBRT_PRIM_PARALLELOGRAM || p.material >= desc->n_materials ||
-            (p.emitter >= 0 && (uint32_t)p.emitter >= desc->n_emitters)) {
+        double cc[3], ca[3], cb[3], cx[3];
+        if (p.type > PBRT_PRIM_CONE || p.material >= desc->n_materials ||
+            (p.emitter >= 0 && (uint32_t)p.emitter >= desc->n_emitters) ||
+            (p.type == PBRT_PRIM_CONE && !cone_frame(p, cc, ca, cb, cx))) {
             delete s;
-            return p.type > PBRT_PRIM_PARALLELOGRAM ? PBRT_E_UNSUPPORTED : PBRT_E_INVALID;
+            return p.type > PBRT_PRIM_CONE ? PBRT_E_UNSUPPORTED : PBRT_E_INVALID;
         }
     }
     s->sc.use_bvh = desc->accel == PBRT_ACCEL_BVH || (desc->accel == PBRT_ACCEL_AUTO && desc->n_prims > 32);

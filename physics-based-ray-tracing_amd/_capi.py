@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbr
 PBRT_ABI_VERSION = 1
 
 # primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
-PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM = 0, 1, 2
+PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
 MAT_DIFFUSE, MAT_CONDUCTOR, MAT_DIELECTRIC, MAT_ULTRA, MAT_NONE = 0, 1, 2, 3, 4
 EMIT_AREA, EMIT_POINT = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2

@@ -23,6 +23,30 @@ struct HostBvh {
     uint32_t max_depth = 0;
 };
 
+// World-space frame of a CONE primitive (g = world -> object 3x4): base centre c, the images a, b of the object x / y
+// unit vectors (the base disc is c + a cos + b sin), and the apex.  False if the matrix is singular or not finite.
+inline bool cone_world_frame(const pbrt_prim &P, double c[3], double a[3], double b[3], double apex[3]) {
+    const double m[3][3] = {{P.g[0], P.g[1], P.g[2]}, {P.g[4], P.g[5], P.g[6]}, {P.g[8], P.g[9], P.g[10]}};
+    const double t[3] = {P.g[3], P.g[7], P.g[11]};
+    const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                       m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+    if (!std::isfinite(det) || det == 0.0) return false;
+    double inv[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            inv[j][i] = (m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1]) / det;  // cofactor transpose
+        }
+    for (int k = 0; k < 3; ++k) {
+        c[k] = -(inv[k][0] * t[0] + inv[k][1] * t[1] + inv[k][2] * t[2]);  // W (0, 0, 0)
+        a[k] = inv[k][0];
+        b[k] = inv[k][1];
+        apex[k] = c[k] + inv[k][2];
+        if (!std::isfinite(c[k]) || !std::isfinite(a[k]) || !std::isfinite(b[k]) || !std::isfinite(apex[k])) return false;
+    }
+    return true;
+}
+
 namespace bvh_detail {
 
 struct Box {
@@ -45,6 +69,16 @@ inline Box prim_box(const pbrt_prim &P) {
         for (int k = 0; k < 3; ++k) {
             b.lo[k] = P.g[k] - P.g[3];
             b.hi[k] = P.g[k] + P.g[3];
+        }
+        return b;
+    }
+    if (P.type == PBRT_PRIM_CONE) {  // hull of the base ellipse and the apex (padded like every box by the builder)
+        double c[3], a[3], bb[3], apex[3];
+        cone_world_frame(P, c, a, bb, apex);  // validated at scene creation
+        for (int k = 0; k < 3; ++k) {
+            const double r = std::sqrt(a[k] * a[k] + bb[k] * bb[k]);
+            b.lo[k] = std::nextafter((float)std::min(c[k] - r, apex[k]), -INFINITY);
+            b.hi[k] = std::nextafter((float)std::max(c[k] + r, apex[k]), INFINITY);
         }
         return b;
     }

@@ -49,6 +49,49 @@ struct Hit {
 
 DEV V3 g3(const pbrt_prim &P, int i) { return {P.g[i], P.g[i + 1], P.g[i + 2]}; }
 
+// Analytic cone ('cone' shapes of MitsubaScenes/Cone_Box.xml:36-47; [DEFINE] D8): the ray goes to object space
+// through the primitive's world -> object matrix (t is preserved, the direction is not re-normalised), there the
+// closed unit cone is the quadric x^2 + y^2 = (1 - z)^2 cut to 0 <= z <= 1 plus the base disc z = 0, r <= 1.
+// Roots by the cancellation-free form q = -(b + sign(b) sqrt(disc)), t = q / A, C / q (a ray parallel to the
+// lateral surface has A = 0: q / A is +-inf or NaN and fails the range tests, C / q is its one crossing).
+// *flag = 0: lateral surface, 1: base disc.  Identical arithmetic in the oracle's cone_hit.
+DEV bool cone_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *flag) {
+    const V3 r0 = g3(P, 0), r1 = g3(P, 4), r2 = g3(P, 8);
+    const V3 oo = {dot(r0, o) + P.g[3], dot(r1, o) + P.g[7], dot(r2, o) + P.g[11]};
+    const V3 dd = {dot(r0, d), dot(r1, d), dot(r2, d)};
+    const float ow = 1.0f - oo.z;  // w = 1 - z, dw = -dz
+    const float A = fma_(dd.x, dd.x, fma_(dd.y, dd.y, -(dd.z * dd.z)));
+    const float b = fma_(oo.x, dd.x, fma_(oo.y, dd.y, ow * dd.z));
+    const float C = fma_(oo.x, oo.x, fma_(oo.y, oo.y, -(ow * ow)));
+    const float disc = fma_(b, b, -(A * C));
+    float best = tmax;
+    float fl = 0.0f;
+    bool found = false;
+    if (disc >= 0.0f) {
+        const float q = -(b + copysignf(sqrtf(disc), b));
+        const float ta = q / A, tb = C / q;
+        const float za = fma_(ta, dd.z, oo.z), zb = fma_(tb, dd.z, oo.z);
+        if (ta >= 0.0f && ta <= best && za >= 0.0f && za <= 1.0f) {
+            best = ta;
+            found = true;
+        }
+        if (tb >= 0.0f && tb <= best && zb >= 0.0f && zb <= 1.0f && (!found || tb < best)) {
+            best = tb;
+            found = true;
+        }
+    }
+    const float tc = -oo.z / dd.z;  // base plane; dz = 0: +-inf or NaN, rejected below
+    const float x = fma_(tc, dd.x, oo.x), y = fma_(tc, dd.y, oo.y);
+    if (tc >= 0.0f && tc <= best && fma_(x, x, y * y) <= 1.0f && (!found || tc < best)) {
+        best = tc;
+        fl = 1.0f;
+        found = true;
+    }
+    *t = best;
+    *flag = fl;
+    return found;
+}
+
 // One primitive against one ray; identical arithmetic to the oracle's prim_hit (Mitsuba
 // Mesh::ray_intersect_triangle / Sphere / Rectangle reached via scene.ray_intersect,
 // CustomIntegrator.py:309).  The barycentric test runs on det-scaled values so that the division
@@ -102,6 +145,10 @@ DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u
         *v = vs * inv;
         return true;
     }
+    if (type == PBRT_PRIM_CONE) {
+        *v = 0.0f;
+        return cone_hit(P, o, d, tmax, t, u);
+    }
     return false;
 }
 
@@ -127,7 +174,10 @@ DEV pbrt_prim load_prim_uniform(const pbrt_prim *p) {
     return __builtin_bit_cast(pbrt_prim, r);
 }
 
-template <bool ANY, bool SEGMENT = false>
+// CONES: the kernel variant understands PBRT_PRIM_CONE records.  Compile-time, because the cone branch costs the
+// 64-VGPR brute-force radiance kernel 9 VGPRs and puts it into scratch (measured: 54 / 60 -> 63 VGPRs + 4 spilled);
+// small scenes with a cone run the ACCEL_K_BRUTE_BIG variant instead (pbrt_api.hip).
+template <bool ANY, bool SEGMENT = false, bool CONES = true>
 DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     bool found = false;
     float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
@@ -146,12 +196,12 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
         const uint32_t type = P.type;  // wave-uniform
         bool ok;
         float num, den, us, vs;
-        if (type == PBRT_PRIM_SPHERE) {
+        if (type == PBRT_PRIM_SPHERE || (CONES && type == PBRT_PRIM_CONE)) {  // curved primitives report (t, 1)
             float t, u, v;
             ok = prim_hit(P, o, d, tmax, &t, &u, &v);
             num = t;
             den = 1.0f;
-            us = 0.0f;
+            us = u;  // 0 for spheres; cone: 0 lateral surface / 1 base disc (den = 1: passes through unscaled)
             vs = 0.0f;
         } else {
             V3 v0 = g3(P, 0), e1 = g3(P, 3), e2 = g3(P, 6);
@@ -283,6 +333,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
 struct SI {
     V3 p, n;
 };
+template <bool CONES = true>
 DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
     SI si;
     if (P.type == PBRT_PRIM_SPHERE) {
@@ -290,6 +341,18 @@ DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
         V3 p = madd(d, t, o);
         si.n = normalize(p - c);
         si.p = madd(si.n, P.g[3], c);
+    } else if (CONES && P.type == PBRT_PRIM_CONE) {
+        // outward normal: object-space gradient of x^2 + y^2 - (1 - z)^2 (lateral) or -z (base disc), to world
+        // space by the transpose of the world -> object matrix
+        const V3 r0 = g3(P, 0), r1 = g3(P, 4), r2 = g3(P, 8);
+        si.p = madd(d, t, o);
+        V3 no = {0.0f, 0.0f, -1.0f};
+        if (u == 0.0f) {
+            no = {dot(r0, si.p) + P.g[3], dot(r1, si.p) + P.g[7], 1.0f - (dot(r2, si.p) + P.g[11])};
+            if (!(dot(no, no) > 0.0f)) no = {0.0f, 0.0f, 1.0f};  // the apex itself
+        }
+        si.n = normalize(v3(fma_(r0.x, no.x, fma_(r1.x, no.y, r2.x * no.z)), fma_(r0.y, no.x, fma_(r1.y, no.y, r2.y * no.z)),
+                            fma_(r0.z, no.x, fma_(r1.z, no.y, r2.z * no.z))));
     } else {
         si.p = madd(g3(P, 6), v, madd(g3(P, 3), u, g3(P, 0)));
         si.n = g3(P, 9);

@@ -46,7 +46,8 @@ __host__ __device__ constexpr uint32_t us_region_segs(int) { return REGION_SEGS_
 #define N_STATE 15
 #define MAX_DEPTH_STATS 62
 
-// ACCEL_K_BRUTE      uniform primitive loop (scalar loads) + shading tables staged in LDS; every table <= 32 entries
+// ACCEL_K_BRUTE      uniform primitive loop (scalar loads) + shading tables staged in LDS; every table <= 32 entries,
+//                    no analytic cones (device_scene.h brute_intersect CONES)
 // ACCEL_K_BVH_GLOBAL stackless BVH, nodes / primitives through the vector caches (scene larger than LDS)
 // ACCEL_K_BVH_LDS    stackless BVH, nodes + primitives + ids staged in LDS per workgroup
 // ACCEL_K_BRUTE_BIG  uniform primitive loop, tables in global memory (brute force forced on a large scene)
@@ -163,7 +164,8 @@ struct LdsScene {
 // scenes then only walk the primitives that can occlude such a segment (DevScene::occ_prims).
 template <int ACCEL, bool ANY, bool SEGMENT = false>
 DEV bool scene_intersect(const DevScene &sc, const LdsScene &ls, V3 o, V3 d, float tmax, Hit *h) {
-    if (ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG) return brute_intersect<ANY, SEGMENT>(sc, o, d, tmax, h);
+    if (ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG)
+        return brute_intersect<ANY, SEGMENT, ACCEL != ACCEL_K_BRUTE>(sc, o, d, tmax, h);
     if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(sc.nodes, sc.prims, sc.prim_ids, o, d, tmax, h);
     return bvh_intersect<ANY>(ls.nodes, ls.prims, ls.ids, o, d, tmax, h);
 }
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, tmax, &h)) {
             did_seg = true;
             const pbrt_prim &P = tb.prims_by_slot[h.slot];
-            SI si = make_si(P, o, d, h.t, h.u, h.v);
+            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
             const int32_t emitter = P.emitter;
             const uint32_t mat_id = P.material;
             // ---- direct emission (one-sided area emitters), MIS against emitter sampling

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         if (hit) {
             did_seg = true;
             const pbrt_prim &P = tb.prims_by_slot[h.slot];
-            SI si = make_si(P, o, d, h.t, h.u, h.v);
+            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
             const float distance = h.t;                                                // :314
             geo_len += distance;                                                       // :315
             const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;

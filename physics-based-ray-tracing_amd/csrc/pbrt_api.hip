@@ -129,6 +129,15 @@ static std::vector<pbrt_prim> find_occluders(const pbrt_scene_desc *d) {
                     double s = side(Q.g[0], Q.g[1], Q.g[2]);
                     acc(s - (double)Q.g[3]);
                     acc(s + (double)Q.g[3]);
+                } else if (Q.type == PBRT_PRIM_CONE) {  // extent of the base ellipse along n, and the apex
+                    double cc[3], ca[3], cb[3], cx[3];
+                    cone_world_frame(Q, cc, ca, cb, cx);
+                    const double s = side(cc[0], cc[1], cc[2]);
+                    const double an = n[0] * ca[0] + n[1] * ca[1] + n[2] * ca[2], bn = n[0] * cb[0] + n[1] * cb[1] + n[2] * cb[2];
+                    const double r = std::sqrt(an * an + bn * bn) * (1.0 + 1e-12);
+                    acc(s - r);
+                    acc(s + r);
+                    acc(side(cx[0], cx[1], cx[2]));
                 } else {
                     const double v0[3] = {Q.g[0], Q.g[1], Q.g[2]}, e1[3] = {Q.g[3], Q.g[4], Q.g[5]}, e2[3] = {Q.g[6], Q.g[7], Q.g[8]};
                     acc(side(v0[0], v0[1], v0[2]));
@@ -220,8 +229,12 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     NEED(c, d->n_light_prims == 0 || (d->light_prims && d->light_cdf));
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const pbrt_prim &p = d->prims[i];
-        if (p.type > PBRT_PRIM_PARALLELOGRAM)
-            return c->fail(PBRT_E_UNSUPPORTED, "primitive %u: type %u is not supported (cone: SURVEY 8 f-4)", i, p.type);
+        if (p.type > PBRT_PRIM_CONE) return c->fail(PBRT_E_UNSUPPORTED, "primitive %u: type %u is not supported", i, p.type);
+        if (p.type == PBRT_PRIM_CONE) {
+            double cc[3], ca[3], cb[3], cx[3];
+            if (!cone_world_frame(p, cc, ca, cb, cx))
+                return c->fail(PBRT_E_INVALID, "primitive %u: cone needs an invertible, finite world -> object matrix", i);
+        }
         if (p.material >= d->n_materials) return c->fail(PBRT_E_INVALID, "primitive %u: material out of range", i);
         if (p.emitter >= 0 && (uint32_t)p.emitter >= d->n_emitters)
             return c->fail(PBRT_E_INVALID, "primitive %u: emitter out of range", i);
@@ -233,7 +246,7 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
                 return c->fail(PBRT_E_INVALID, "emitter %u: light primitive range out of bounds", i);
             for (uint32_t k = 0; k < e.count; ++k) {
                 uint32_t pi = d->light_prims[e.first + k];
-                if (pi >= d->n_prims || d->prims[pi].type == PBRT_PRIM_SPHERE)
+                if (pi >= d->n_prims || d->prims[pi].type == PBRT_PRIM_SPHERE || d->prims[pi].type == PBRT_PRIM_CONE)
                     return c->fail(PBRT_E_UNSUPPORTED, "emitter %u: area lights need triangle/parallelogram primitives", i);
             }
         } else if (e.type != PBRT_EMIT_POINT) {
@@ -269,7 +282,9 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         s->ds.prim_ids = nullptr;
         s->ds.nodes = nullptr;
         s->ds.n_nodes = 0;
-        const bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
+        bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
+        for (uint32_t i = 0; i < d->n_prims; ++i)
+            if (d->prims[i].type == PBRT_PRIM_CONE) small = false;  // only the _BIG variant carries the cone code
         s->accel_kernel = small ? ACCEL_K_BRUTE : ACCEL_K_BRUTE_BIG;
         std::vector<pbrt_prim> occ = find_occluders(d);
         UP(upload(s, occ.data(), occ.size(), &s->ds.occ_prims));
@@ -976,7 +991,7 @@ int pbrt_ray_intersect(pbrt_scene *s, uint32_t n, const float *o, const float *d
     float *rt = S.out<float>(n), *ru = S.out<float>(n), *rv = S.out<float>(n);
     uint32_t *rp = S.out<uint32_t>(n);
     if (s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG)
-        hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
+        hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BRUTE_BIG>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
     else
         hipLaunchKernelGGL(k_ray_intersect<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rt, rp, ru, rv);
     S.back(t, rt, n);
@@ -993,7 +1008,7 @@ int pbrt_ray_test(pbrt_scene *s, uint32_t n, const float *o, const float *d, con
     float *dO = S.in(o, 3 * (size_t)n), *dD = S.in(d, 3 * (size_t)n), *dT = S.in(tmax, n);
     uint8_t *rh = S.out<uint8_t>(n);
     if (s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG)
-        hipLaunchKernelGGL(k_ray_test<ACCEL_K_BRUTE>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
+        hipLaunchKernelGGL(k_ray_test<ACCEL_K_BRUTE_BIG>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
     else
         hipLaunchKernelGGL(k_ray_test<ACCEL_K_BVH_GLOBAL>, grid, block, 0, st, s->ds, n, dO, dD, dT, rh);
     S.back(hit, rh, n);

@@ -241,20 +241,35 @@ class RectangleShape(Shape):
 class ConeShape(Shape):
     """'cone' (MitsubaScenes/Cone_Box.xml:36-47, Cone_FLoating.xml) has no Mitsuba-3 definition.
     [DEFINE]: the closed unit cone -- apex (0, 0, 1), base disc of radius 1
-    in the plane z = 0 -- under to_world, tessellated on the host (outward face normals), so it takes the BVH
-    path like any other mesh and non-uniform to_world scales (Cone_Box.xml: 0.06 / 0.06 / 0.10) need no special
-    case.  `segments` around the axis, `rings` along it and across the base disc: plain fans from the apex / the
-    centre are 2 x `segments` slivers whose boxes all overlap (measured: 3 x slower traversal than the ring scene
-    with 4 x fewer triangles), so both surfaces are cut into rings of quads with a fan only in the innermost ring."""
+    in the plane z = 0 -- under to_world (any affine map; Cone_Box.xml scales by 0.06 / 0.06 / 0.10).
+    One analytic PRIM_CONE record carrying the world -> object matrix (the kernels intersect the quadric in object
+    space), so a cone phantom stays on the brute-force path.  `tessellate=true` builds a triangle mesh instead
+    (BVH path): `segments` around the axis, `rings` along it and across the base disc -- plain fans from the apex /
+    the centre are 2 x `segments` slivers whose boxes all overlap, so both surfaces are cut into rings of quads with
+    a fan only in the innermost ring.  (Measured on the Cone_Box phantom: 9.3 ms tessellated)"""
 
     def __init__(self, props):
         super().__init__(props)
+        self.tessellate = bool(props.get("tessellate", False))
         self.segments = int(props.get("segments", 64))
         self.rings = int(props.get("rings", 4))
         if self.segments < 3 or self.rings < 1:
             raise ValueError("cone: segments must be >= 3 and rings >= 1")
+        if abs(np.linalg.det(self.to_world.matrix[:3, :3])) < 1e-300:
+            raise ValueError("cone: to_world must be invertible")
 
     def primitives(self):
+        if not self.tessellate:
+            rec = np.zeros(1, dtype=_capi.PRIM_DTYPE)
+            M = self.to_world.matrix.astype(np.float64)
+            if self.flip_normals:   # the record has no orientation bit; the mesh form has (triangle winding)
+                raise NotImplementedError("cone: flip_normals needs tessellate=true")
+            rec["g"][0] = np.linalg.inv(M)[:3, :4].reshape(12)
+            rec["type"] = _capi.PRIM_CONE
+            return rec
+        return self._mesh_primitives()
+
+    def _mesh_primitives(self):
         n, R = self.segments, self.rings
         ang = 2.0 * np.pi * np.arange(n, dtype=np.float64) / n
         c, s = np.cos(ang), np.sin(ang)
@@ -438,8 +453,8 @@ class Scene(Object):
             if em is None:
                 continue
             rec = prim_blocks[si]
-            if np.any(rec["type"] == _capi.PRIM_SPHERE):
-                raise NotImplementedError("area emitters on spheres are not supported yet")
+            if np.any((rec["type"] == _capi.PRIM_SPHERE) | (rec["type"] == _capi.PRIM_CONE)):
+                raise NotImplementedError("area emitters on spheres / analytic cones are not supported")
             e1 = rec["g"][:, 3:6].astype(np.float64)
             e2 = rec["g"][:, 6:9].astype(np.float64)
             area = np.linalg.norm(np.cross(e1, e2), axis=1)
@@ -538,6 +553,18 @@ class Scene(Object):
             ns = ns / np.maximum(np.linalg.norm(ns, axis=1, keepdims=True), 1e-30)
             p = np.where(sph[:, None], g[:, 0:3] + ns * g[:, 3:4], p)
             nrm = np.where(sph[:, None], ns, nrm)
+        cone = (typ == _capi.PRIM_CONE) & valid
+        if np.any(cone):   # same formulas as make_si: p = o + t d, n = M^T (object-space gradient | -z)
+            M = g.reshape(-1, 3, 4).astype(np.float64)
+            pc = o + np.where(cone, t, 0.0)[:, None] * d
+            q = np.einsum("nij,nj->ni", M[:, :, :3], pc) + M[:, :, 3]
+            no = np.stack([q[:, 0], q[:, 1], 1.0 - q[:, 2]], axis=1)
+            no[np.einsum("ni,ni->n", no, no) == 0] = [0.0, 0.0, 1.0]
+            no[u != 0] = [0.0, 0.0, -1.0]
+            nw = np.einsum("nji,nj->ni", M[:, :, :3], no)
+            nw = nw / np.maximum(np.linalg.norm(nw, axis=1, keepdims=True), 1e-300)
+            p = np.where(cone[:, None], pc, p)
+            nrm = np.where(cone[:, None], nw, nrm)
         p[~valid] = 0
         nrm[~valid] = 0
         return dict(p=p.astype(np.float32), n=nrm.astype(np.float32), shape=np.where(valid, P["shape"][idx], -1))

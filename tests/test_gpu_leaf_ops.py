@@ -18,7 +18,8 @@ def _rays(n, seed, lo, hi):
 
 @pytest.mark.parametrize("scene,kw,lo,hi", [("cbox.xml", dict(res=8), -0.95, 0.95), ("simple.xml", dict(res=8, spp=1), -6, 6),
                                             ("testring.xml", dict(res=8), -0.1, 0.1), ("us_sphere_box.xml", {}, -0.14, 0.14),
-                                            ("us_cone_box.xml", {}, -0.14, 0.14)])
+                                            ("us_cone_box.xml", {}, -0.14, 0.14),                         # analytic cone
+                                            ("us_cone_box.xml", dict(tessellate="true"), -0.14, 0.14)])   # 896 triangles
 def test_ray_intersect_and_ray_test(mi, ob, scene, kw, lo, hi):
     sc = mi.load_file(scene_path(scene), **kw)
     n = 20000
@@ -40,13 +41,54 @@ def test_ray_intersect_and_ray_test(mi, ob, scene, kw, lo, hi):
 def test_axis_aligned_rays_through_shared_vertices(mi, ob):
     """zero direction components and origins in box faces (0 * inf in a slab test): the probe axis meets the centre
     vertex of the cone's base fan, shared by 96 triangles -- found, and the same primitive as the oracle picks"""
-    sc = mi.load_file(scene_path("us_cone_box.xml"))
     o = np.array([[0, 0, 0], [0, 0, 0], [0.001, 0, 0], [0, 0, 0.2], [0.15, 0, 0.1]], np.float32)
     d = np.array([[0, 0, 1], [0, 1, 0], [0, 0, 1], [0, 0, -1], [-1, 0, 0]], np.float32)
-    got = sc.ray_intersect(o, d)
-    t, prim, u, v = ob.OracleScene.from_scene(sc).ray_intersect(o, d, np.full(5, np.inf, np.float32))
-    assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"], t)
-    assert got["valid"].all() and got["t"][0] == pytest.approx(0.06, rel=1e-5)
+    for kw in (dict(tessellate="true"), {}):     # the mesh, and the analytic cone (base disc centre at (0, 0, 0.06))
+        sc = mi.load_file(scene_path("us_cone_box.xml"), **kw)
+        got = sc.ray_intersect(o, d)
+        t, prim, u, v = ob.OracleScene.from_scene(sc).ray_intersect(o, d, np.full(5, np.inf, np.float32))
+        assert np.array_equal(got["prim"], prim) and np.array_equal(got["t"], t)
+        assert got["valid"].all() and got["t"][0] == pytest.approx(0.06, rel=1e-5)
+
+
+def test_unit_cone_known_hits_and_normals(mi):
+    """analytic cone (closed unit cone under to_world): hand-computed hits, outward normals on the lateral surface
+    and the base disc, also under a mirrored, non-uniformly scaled to_world"""
+    s = 1 / np.sqrt(2)
+    sc = mi.load_dict({"type": "scene", "c": {"type": "cone"}})
+    r = sc.ray_intersect([[0, 0, -1], [2, 0, 0.5], [0, 0, 0.5], [0.25, 0.25, 0.25], [2, 0, 2], [0, 3, 0.5]],
+                         [[0, 0, 1], [-1, 0, 0], [1, 0, 0], [0, 0, -1], [-1, 0, 0], [0, 1, 0]])
+    assert list(r["valid"]) == [True, True, True, True, False, False]
+    assert np.allclose(r["t"][:4], [1.0, 1.5, 0.5, 0.25], rtol=2e-6)
+    assert np.allclose(r["n"][:4], [[0, 0, -1], [s, 0, s], [s, 0, s], [0, 0, -1]], atol=1e-6)
+    assert np.allclose(r["p"][:4], [[0, 0, 0], [0.5, 0, 0.5], [0.5, 0, 0.5], [0.25, 0.25, 0]], atol=1e-6)
+    T = mi.ScalarTransform4f
+    tw = T().translate([0.5, -1, 2]) @ T().rotate([1, 2, 3], 40) @ T().scale([-0.5, 2, 3])
+    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "to_world": tw}})
+    M = tw.matrix
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1, 1, (12000, 3)) * [1.5, 1.5, 1] + [0, 0, 0.5]             # object-space origins around the cone
+    o = q @ M[:3, :3].T + M[:3, 3]
+    d = rng.normal(size=(12000, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    r = sc.ray_intersect(o, d)
+    hit = r["valid"]
+    assert 0.08 < hit.mean() < 0.9
+    Wi = np.linalg.inv(M)
+    po = r["p"][hit].astype(np.float64) @ Wi[:3, :3].T + Wi[:3, 3]                 # hit points back in object space
+    on_base = np.abs(po[:, 2]) < 1e-5
+    on_side = np.abs(np.hypot(po[:, 0], po[:, 1]) - (1 - po[:, 2])) < 1e-4
+    assert np.all(on_base | on_side) and on_base.sum() > 50 and on_side.sum() > 200
+    # outward: the object-space image of the normal (covariant: n_obj ~ M^T n_world) is -z on the base and has a
+    # positive radial component on the lateral surface
+    no = r["n"][hit].astype(np.float64) @ M[:3, :3]
+    no /= np.linalg.norm(no, axis=1, keepdims=True)
+    pure_base = on_base & ~on_side
+    assert np.allclose(no[pure_base], [0, 0, -1], atol=1e-5)
+    side = on_side & ~on_base & (po[:, 2] < 0.98)
+    want = np.stack([po[side, 0], po[side, 1], 1 - po[side, 2]], axis=1)
+    want /= np.linalg.norm(want, axis=1, keepdims=True)
+    assert np.allclose(no[side], want, atol=2e-4)
 
 
 def test_empty_and_single_batches(mi):

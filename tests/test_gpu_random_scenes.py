@@ -1,5 +1,5 @@
-"""Randomised geometry: spheres, rectangles (parallelograms) and triangle meshes in random poses, small scenes (brute
-force) and large ones (BVH), random rays -- the closest hit, the occlusion test and a short render equal the oracle's
+"""Randomised geometry: spheres, rectangles (parallelograms), analytic cones and triangle meshes in random poses, small
+scenes (brute force) and large ones (BVH), random rays -- the closest hit, the occlusion test and a short render equal the oracle's
 bit for bit.  Seeds are fixed: the cases are reproducible."""
 import numpy as np
 import pytest
@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _random_scene(mi, tmp_path, seed, n_spheres, n_rects, n_tris):
+def _random_scene(mi, tmp_path, seed, n_spheres, n_rects, n_tris, n_cones=0):
     rng = np.random.default_rng(seed)
     T = mi.ScalarTransform4f
     d = {"type": "scene", "integrator": {"type": "path", "max_depth": 4},
@@ -25,6 +25,11 @@ def _random_scene(mi, tmp_path, seed, n_spheres, n_rects, n_tris):
         tw = T().translate(list(rng.uniform(-2, 2, 3))) @ T().rotate(list(rng.normal(size=3)), float(rng.uniform(0, 360))) @ \
             T().scale([float(rng.uniform(0.3, 1.2)), float(rng.uniform(0.3, 1.2)), 1])
         d[f"r{i}"] = {"type": "rectangle", "to_world": tw, "bsdf": mats[0]}
+    for i in range(n_cones):   # any affine pose: non-uniform scale, every other one mirrored
+        sx = float(rng.uniform(0.3, 0.9)) * (-1 if i % 2 else 1)
+        tw = T().translate(list(rng.uniform(-2, 2, 3))) @ T().rotate(list(rng.normal(size=3)), float(rng.uniform(0, 360))) @ \
+            T().scale([sx, float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.4, 1.5))])
+        d[f"c{i}"] = {"type": "cone", "to_world": tw, "bsdf": mats[i % 3]}
     if n_tris:
         v = rng.uniform(-2.5, 2.5, (n_tris, 1, 3)) + rng.normal(scale=0.25, size=(n_tris, 3, 3))
         path = tmp_path / f"soup{seed}.obj"
@@ -37,9 +42,10 @@ def _random_scene(mi, tmp_path, seed, n_spheres, n_rects, n_tris):
     return mi.load_dict(d)
 
 
-@pytest.mark.parametrize("seed,ns,nr,nt", [(1, 3, 4, 0), (2, 5, 10, 12), (3, 0, 2, 400), (4, 6, 6, 1500)])
-def test_random_scene_leaf_ops_and_render(mi, ob, capi, tmp_path, seed, ns, nr, nt):
-    sc = _random_scene(mi, tmp_path, seed, ns, nr, nt)
+@pytest.mark.parametrize("seed,ns,nr,nt,nc", [(1, 3, 4, 0, 0), (2, 5, 10, 12, 0), (3, 0, 2, 400, 0), (4, 6, 6, 1500, 0),
+                                              (5, 2, 4, 0, 4), (6, 3, 5, 300, 5)])     # cones: brute force / in BVH leaves
+def test_random_scene_leaf_ops_and_render(mi, ob, capi, tmp_path, seed, ns, nr, nt, nc):
+    sc = _random_scene(mi, tmp_path, seed, ns, nr, nt, nc)
     n_prims = len(sc.flatten()["prims"])
     assert (n_prims <= 32) == (nt <= 12)                       # both accelerators are exercised across the cases
     rng = np.random.default_rng(100 + seed)

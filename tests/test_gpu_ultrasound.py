@@ -27,9 +27,11 @@ def check(buf, ref):
     assert np.array_equal(buf != 0, ref != 0)
 
 
-@pytest.mark.parametrize("scene,ppr,seed", [("us_plate.xml", 64, 0), ("us_plate.xml", 500, 3), ("us_sphere_box.xml", 200, 1), ("us_cone_box.xml", 100, 2)])
-def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed):
-    sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed)
+@pytest.mark.parametrize("scene,ppr,seed,kw", [("us_plate.xml", 64, 0, {}), ("us_plate.xml", 500, 3, {}), ("us_sphere_box.xml", 200, 1, {}),
+                                               ("us_cone_box.xml", 100, 2, {}),                          # analytic cone, brute force
+                                               ("us_cone_box.xml", 100, 2, dict(tessellate="true"))])    # 901 triangles, BVH
+def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed, kw):
+    sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed, **kw)
     ui = sc.integrator()
     assert ui.simulate_acquisition_parallel(sc) is True                # CustomIntegrator.py:405
     ref, tx = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), seed, ppr)
@@ -145,11 +147,11 @@ def test_random_phantoms_match_oracle(mi, ob, capi, seed, n_spheres, n_plates, q
     assert (ref != 0).sum() > 50
 
 
-@pytest.mark.parametrize("scene", ["us_sphere_box.xml", "us_cone_box.xml"])
-def test_first_bounce_tables_change_nothing(mi, capi, scene):
+@pytest.mark.parametrize("scene,kw", [("us_sphere_box.xml", {}), ("us_cone_box.xml", {}), ("us_cone_box.xml", dict(tessellate="true"))])
+def test_first_bounce_tables_change_nothing(mi, capi, scene, kw):
     """the shared first hit / visibility tables (k_us_first) against every path walking the scene itself: the same
     arithmetic, so the same channel buffer up to the order of the float additions"""
-    sc = mi.load_file(scene_path(scene), paths_per_ray=128, seed=8)
+    sc = mi.load_file(scene_path(scene), paths_per_ray=128, seed=8, **kw)
     ui = sc.integrator()
     with_tables = ui._acquire(sc, ui.quirks)
     without = ui._acquire(sc, ui.quirks | capi.USQ_NO_FIRST_TABLES)

@@ -160,7 +160,7 @@ def test_bvh_equals_brute_force(mi, ob, capi):
         assert np.array_equal(x, y)
     assert (A[1] != 0xFFFFFFFF).sum() > 100
     # tessellated cone phantom: the ray up the probe axis meets the cone where the closed form says
-    sc = mi.load_file(scene_path("us_cone_box.xml"))
+    sc = mi.load_file(scene_path("us_cone_box.xml"), tessellate="true")
     osc = ob.OracleScene.from_scene(sc, capi.ACCEL_BVH)
     t, prim, *_ = osc.ray_intersect(np.array([[0, 0, 0]], np.float32), np.array([[0, 0, 1]], np.float32), np.array([np.inf], np.float32))
     M = [s for s in sc.shapes() if s.id() == "cone"][0].to_world.matrix

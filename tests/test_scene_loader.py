@@ -219,15 +219,18 @@ def test_unknown_plugin_is_loud(mi):
 
 
 def test_cone_definition(mi):
-    """'cone' = closed unit cone (apex (0,0,1), base disc r = 1 at z = 0) under to_world, tessellated."""
-    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "segments": 64, "rings": 1}})   # plain fans
+    """'cone' = closed unit cone (apex (0,0,1), base disc r = 1 at z = 0) under to_world: one analytic record by default
+    (tests/test_oracle_cone.py), a triangle mesh with tessellate=True."""
+    one = mi.load_dict({"type": "scene", "c": {"type": "cone"}}).flatten()["prims"]
+    assert len(one) == 1 and one["type"][0] == 3 and np.array_equal(one["g"][0].reshape(3, 4), np.eye(4, dtype=np.float32)[:3])
+    sc = mi.load_dict({"type": "scene", "c": {"type": "cone", "tessellate": True, "segments": 64, "rings": 1}})   # plain fans
     P = sc.flatten()["prims"]
     assert len(P) == 128 and np.all(P["type"] == 0)
     v0, e1, e2, n = (P["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6, 9))
     assert np.allclose((v0 + e2)[:64], [0, 0, 1]) and np.allclose(v0[64:], [0, 0, 0])    # lateral fan to the apex, base fan
     assert np.allclose(np.linalg.norm(v0[:64, :2], axis=1), 1) and np.allclose(v0[:64, 2], 0)
     for kw in (dict(segments=64, rings=1), dict(), dict(segments=24, rings=5)):           # default: 64 segments x 4 rings
-        P = mi.load_dict({"type": "scene", "c": {"type": "cone", **kw}}).flatten()["prims"]
+        P = mi.load_dict({"type": "scene", "c": {"type": "cone", "tessellate": True, **kw}}).flatten()["prims"]
         S, R = kw.get("segments", 64), kw.get("rings", 4)
         assert len(P) == 2 * S * (2 * R - 1)
         v0, e1, e2, n = (P["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6, 9))
@@ -239,7 +242,8 @@ def test_cone_definition(mi):
         vol = np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6                      # divergence theorem: closed, outward
         assert vol == pytest.approx(np.pi / 3, rel=2.5e-2 if S < 64 else 2e-3)
     # the reference's phantom (intent transform): base centre, apex, non-uniform scale
-    sc = mi.load_file(scene_path("us_cone_box.xml"))
+    assert len(mi.load_file(scene_path("us_cone_box.xml")).flatten()["prims"]) == 6      # analytic cone + 5 walls
+    sc = mi.load_file(scene_path("us_cone_box.xml"), tessellate="true")
     P = sc.flatten()["prims"]
     c = P[P["shape"] == [s.id() for s in sc.shapes()].index("cone")]
     assert len(c) == 896 and len(P) == 901
@@ -249,7 +253,7 @@ def test_cone_definition(mi):
     v0, e1, e2 = (c["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6))
     assert np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) / 6 == pytest.approx(np.pi * 0.06 * 0.06 * 0.10 / 3, rel=2e-3)
     # a mirrored to_world keeps the normals outward
-    m = mi.load_dict({"type": "scene", "c": {"type": "cone", "to_world": mi.ScalarTransform4f().scale([1, -1, 1])}})
+    m = mi.load_dict({"type": "scene", "c": {"type": "cone", "tessellate": True, "to_world": mi.ScalarTransform4f().scale([1, -1, 1])}})
     Q = m.flatten()["prims"]
     v0, e1, e2 = (Q["g"][:, i:i + 3].astype(np.float64) for i in (0, 3, 6))
     assert np.sum(np.einsum("ij,ij->i", v0, np.cross(e1, e2))) > 0
@@ -266,4 +270,4 @@ def test_reference_phantoms_all_load(mi):
         P = sc.flatten()["prims"]
         assert len(P) >= 1 and type(sc.integrator()).__name__ == "UltraIntegrator"
         if "Cone" in f:
-            assert (P["type"] == 0).sum() == 896
+            assert (P["type"] == 3).sum() == 1

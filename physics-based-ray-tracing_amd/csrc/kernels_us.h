@@ -30,6 +30,7 @@ struct UsArgs {
     uint32_t ppr_pass, path_first;  // paths per ray in this pass, global index of local path 0
     uint32_t lds_bytes;
     uint32_t stat_stride;
+    uint32_t fuse;  // bounces a.depth .. max_depth - 1 in this launch (k_us_bounce<false>)
     // First-bounce tables (k_us_first): the primary ray of an (angle, element) pair is deterministic
     // (CustomIntegrator.py:270-273), so all P paths of a ray share the first hit, and the occlusion of the ray to a
     // receive element, the directivity weight, the echo time and its carrier depend on (ray, element) only.  Computed
@@ -116,7 +117,18 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         __syncthreads();
     const uint32_t cap = a.cap;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
-    uint32_t out_off = 0, ns_acc = 0;
+    // Bounces >= 1 run in ONE launch (a.fuse): compaction is local to the region (to the wave for BVH scenes), so the
+    // owner carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers --
+    // no grid-wide barrier per bounce, and no launches for the bounces that find nothing alive (ultrasound paths
+    // die fast: Sphere_Box has 20 % of them left after the first bounce and none after the second, and every one of
+    // the 8 empty launches up to max_depth cost 5 us per pass).
+    const float *in = a.in;
+    float *out = a.out;
+    uint32_t depth = a.depth;
+    uint32_t out_off, ns_acc;
+    for (;;) {  // bounce loop: a single trip unless a.fuse
+    out_off = 0;
+    ns_acc = 0;
     for (uint32_t it0 = 0; it0 < cnt_in; it0 += CH) {
     const uint32_t buf = (it0 / SEG) & 1u;
     const bool alive = it0 + lane_c < cnt_in;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             tof = 0.0f;
             geo_len = 0.0f;                                                            // :276-279
         } else {
-            const float *s = a.in + slot;
+            const float *s = in + slot;
             o = {s[0 * cap], s[1 * cap], s[2 * cap]};
             d = {s[3 * cap], s[4 * cap], s[5 * cap]};
             amp = s[6 * cap];
@@ -150,7 +162,6 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             k = a.path_first + (home - ray_id * a.ppr_pass);
         }
         const uint32_t ang = ray_id / NE;
-        const uint32_t depth = a.depth;
         const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         Hit h;
         bool hit;
@@ -277,7 +288,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         }
     }
     if (survive) {
-        float *s = a.out + base + out_off + off + prefix;
+        float *s = out + base + out_off + off + prefix;
         s[0 * cap] = o.x;
         s[1 * cap] = o.y;
         s[2 * cap] = o.z;
@@ -294,19 +305,30 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     if (!WP && tid == 0)
         for (uint32_t w = 0; w < SEG / 64; ++w) ns_acc += wave_seg[buf][w];
     }  // chunk loop
+    if (WP ? (tid & 63u) == 0 : tid == 0) {
+        unsigned long long *row = a.stats + own;  // per-region / per-wave rows, see k_bounce
+        const size_t stride = a.stat_stride;
+        row[0] += ns_acc;
+        row[stride] += ns_acc;  // one occlusion ray per shaded segment
+        row[(2 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
+    }
+    if (FIRST || !a.fuse || out_off == 0 || depth + 1 >= a.p.max_depth) break;  // uniform over the owner
+    // the survivors just written are the next bounce's input: stores complete (release at workgroup scope; the waves
+    // of a workgroup share the CU's vector L1, so no invalidate), then everybody has finished reading the old input
+    __threadfence_block();
+    if (!WP) __syncthreads();
+    const float *nxt_in = out;
+    out = const_cast<float *>(in);
+    in = nxt_in;
+    cnt_in = out_off;
+    ++depth;
+    }  // bounce loop
     __syncthreads();  // all echoes of the workgroup are in the bins
     for (uint32_t t = tid; t < US_AGG_BINS; t += SEG) {
         const uint32_t ci = agg_idx[t];
         if (ci != 0xffffffffu) atomicAdd(&a.channel[ci], agg_sum[t]);
     }
-    if (WP ? (tid & 63u) == 0 : tid == 0) {
-        a.seg_out[own] = out_off;
-        unsigned long long *row = a.stats + own;  // per-region / per-wave rows, see k_bounce
-        const size_t stride = a.stat_stride;
-        row[0] += ns_acc;
-        row[stride] += ns_acc;  // one occlusion ray per shaded segment
-        row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
-    }
+    if (WP ? (tid & 63u) == 0 : tid == 0) a.seg_out[own] = out_off;
 }
 
 // First-bounce tables, one thread per (ray, receive element): the primary ray, its closest hit, and the occlusion test

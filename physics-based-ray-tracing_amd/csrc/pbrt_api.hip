@@ -817,6 +817,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     a.cap = cap;
     a.seed = seed;
     a.lds_bytes = s->lds_bytes;
+    a.fuse = (p->quirks & PBRT_USQ_NO_FUSED_BOUNCES) ? 0u : 1u;
     // first-bounce tables (kernels_us.h k_us_first): worth it once a ray has more paths than receive elements
     if (ppr >= NE && !(p->quirks & PBRT_USQ_NO_FIRST_TABLES)) {
         float4 *fh = (float4 *)c->buf("us_first_hit", (size_t)n_rays * 16);
@@ -862,6 +863,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
                 launch_us<false>(s, a, nseg_pass);
             HIPCHK(c, hipGetLastError());
             ++launches;
+            if (depth > 0 && a.fuse) break;  // that launch walked every remaining bounce (kernels_us.h)
             std::swap(in, out);
             std::swap(sin, sout);
         }

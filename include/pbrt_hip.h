@@ -190,7 +190,7 @@ typedef struct pbrt_us_params {
 #define PBRT_USQ_NO_CARRIER 0x100u  /* f-3 pulse model: deposit atten*amp*w_i*w_o without the sin(phase) factor of :348; the carrier
                                        comes from pbrt_us_apply_pulse (not a reference quirk)  */
 #define PBRT_USQ_NO_FIRST_TABLES 0x200u /* diagnostic: every path walks the scene at its first bounce (same result) */
-#define PBRT_USQ_NO_FUSED_BOUNCES 0x400u /* diagnostic: one launch per bounce instead of one for all bounces >= 1 */
+#define PBRT_USQ_NO_FUSED_BOUNCES 0x400u /* diagnostic: one launch per bounce instead of one per pass */
 #define PBRT_USQ_REFERENCE                                                                \
     (PBRT_USQ_DIAG_SAMPLE | PBRT_USQ_REF_REFLECT | PBRT_USQ_UNIT_GGX_PDF | PBRT_USQ_DOUBLE_LOCAL | \
      PBRT_USQ_MIXED_FRAMES | PBRT_USQ_NEVER_ENTER)

@@ -117,16 +117,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         __syncthreads();
     const uint32_t cap = a.cap;
     const uint32_t NE = a.p.n_elements, T = a.p.time_samples;
-    // Bounces >= 1 run in ONE launch (a.fuse): compaction is local to the region (to the wave for BVH scenes), so the
-    // owner carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers --
-    // no grid-wide barrier per bounce, and no launches for the bounces that find nothing alive (ultrasound paths
-    // die fast: Sphere_Box has 20 % of them left after the first bounce and none after the second, and every one of
-    // the 8 empty launches up to max_depth cost 5 us per pass).
+    // ALL bounces of a pass run in ONE launch (a.fuse; the FIRST kernel goes on with the later bounces): compaction is
+    // local to the region (to the wave for BVH scenes), so the owner carries its survivors from bounce to bounce on its
+    // own, ping-ponging between the two state buffers -- no grid-wide barrier per bounce, the survivors are re-read
+    // while they are still in L2, and no launches for the bounces that find nothing alive (ultrasound paths die
+    // fast: Sphere_Box has 20 % of them left after the first bounce and none after the second; the 8 empty launches up
+    // to max_depth cost 5 us each per pass).  Config 3: 10.1 ms with one launch per bounce, 9.1 with bounces >= 1
+    // fused, 8.6 with all of them.
     const float *in = a.in;
     float *out = a.out;
     uint32_t depth = a.depth;
     uint32_t out_off, ns_acc;
     for (;;) {  // bounce loop: a single trip unless a.fuse
+    const bool first = FIRST && depth == 0;  // FIRST kernels continue with the later bounces when a.fuse
     out_off = 0;
     ns_acc = 0;
     for (uint32_t it0 = 0; it0 < cnt_in; it0 += CH) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     uint32_t home = slot;
     if (alive) {
         uint32_t ray_id, k;
-        if (FIRST) {
+        if (first) {
             ray_id = home / a.ppr_pass;
             k = a.path_first + (home - ray_id * a.ppr_pass);
             const uint32_t ang = ray_id / NE, el = ray_id - ang * NE;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         Hit h;
         bool hit;
-        if (FIRST && a.first_hit) {  // shared first hit of the ray (k_us_first)
+        if (first && a.first_hit) {  // shared first hit of the ray (k_us_first)
             const float4 r = a.first_hit[ray_id];
             h.t = r.x;
             h.u = r.y;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (!no_acc) tof += distance * a.inv_c;                                    // :316
             F4 u = rng4(ray_id, k, depth, a.seed);
             uint32_t recv = min((uint32_t)(u.x * (float)NE), NE - 1);                  // :319
-            const bool tab = FIRST && a.first_rx != nullptr;  // (ray, receive element) record of k_us_first
+            const bool tab = first && a.first_rx != nullptr;  // (ray, receive element) record of k_us_first
             float4 rx = {0.0f, 0.0f, 0.0f, 0.0f};
             V3 sec_dir = {0.0f, 0.0f, 0.0f};
             bool visible = false;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         row[stride] += ns_acc;  // one occlusion ray per shaded segment
         row[(2 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
     }
-    if (FIRST || !a.fuse || out_off == 0 || depth + 1 >= a.p.max_depth) break;  // uniform over the owner
+    if (!a.fuse || out_off == 0 || depth + 1 >= a.p.max_depth) break;  // uniform over the owner
     // the survivors just written are the next bounce's input: stores complete (release at workgroup scope; the waves
     // of a workgroup share the CU's vector L1, so no invalidate), then everybody has finished reading the old input
     __threadfence_block();

@@ -863,7 +863,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
                 launch_us<false>(s, a, nseg_pass);
             HIPCHK(c, hipGetLastError());
             ++launches;
-            if (depth > 0 && a.fuse) break;  // that launch walked every remaining bounce (kernels_us.h)
+            if (a.fuse) break;  // that launch walked every bounce (kernels_us.h)
             std::swap(in, out);
             std::swap(sin, sout);
         }

@@ -69,6 +69,8 @@ __host__ __device__ constexpr uint32_t seg_waves_per_eu(int accel) {
 __host__ __device__ constexpr bool rad_wave_private(int accel) {
 #ifdef PBRT_BVH_WG_COMPACT  // diagnostic builds only (A/B against the workgroup-level scan)
     return false && accel;
+#elif defined(PBRT_BRUTE_DYN)  // diagnostic builds only: chunk queue for the brute-force kernels as well
+    return accel >= 0;
 #else
     return accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS;
 #endif
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     // are free for the next workgroup's waves (late bounces run at 10-50 % fill).  They publish a zero survivor
     // count first; s_barrier does not wait for terminated waves.
 #ifndef PBRT_ABLATE_EARLY_EXIT
-    constexpr bool early_exit = ACCEL == ACCEL_K_BRUTE && !FIRST && rad_region_segs(ACCEL) == 1;
+    constexpr bool early_exit = ACCEL == ACCEL_K_BRUTE && !FIRST && rad_region_segs(ACCEL) == 1 && !PERWAVE;
 #else
     constexpr bool early_exit = false;
 #endif
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     if (DYN && ACCEL != ACCEL_K_BVH_LDS) __syncthreads();               // publishes the queue words
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
-    if (ACCEL == ACCEL_K_BRUTE && FIRST) fill_tables_lds(a.sc, tab_lds, SEG);
+    if (ACCEL == ACCEL_K_BRUTE && (FIRST || PERWAVE)) fill_tables_lds(a.sc, tab_lds, SEG);  // (PERWAVE: no barrier in the walk)
 
     const uint32_t cap = a.cap;
     const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         }
     }
     // shading tables -> LDS, behind the state loads so that the two memory round trips overlap
-    if (ACCEL == ACCEL_K_BRUTE && !FIRST && it0 == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
+    if (ACCEL == ACCEL_K_BRUTE && !FIRST && !PERWAVE && it0 == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
     if (alive) {
         if (!FIRST) path_key(a, home, &ka, &kb, &px, &py);
         const uint32_t depth = a.depth;

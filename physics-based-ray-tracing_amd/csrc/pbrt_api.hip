@@ -421,7 +421,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
     // BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
-    const bool repack = rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
+    const bool repack = (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) &&
+                        rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
     float *stC = repack ? (float *)c->buf("stateC", (size_t)cap * N_STATE * 4) : nullptr;
     // live counters and statistics rows: one per region, or one per wave of it (BVH kernels: wave-private compaction)
     const uint32_t n_own = nseg * rad_owners_per_region(s->accel_kernel);

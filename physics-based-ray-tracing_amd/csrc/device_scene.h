@@ -265,6 +265,14 @@ DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float h
     return tn <= tf;
 }
 
+// Diagnostic (-DPBRT_BVH_RING=n, default off): n deferred far children are kept in registers (node | level << 24,
+// newest first); a pop takes the newest one and shifts the trail by the level difference instead of climbing the
+// parent links one dependent LDS read per level; the ring forgets its oldest entry on overflow and the climb finds
+// that sibling.  Same visiting order, same result -- and no gain: ring scene 24.0 ms without, 27.2 / 25.6 / 25.0 /
+// 25.3 ms with 2 / 3 / 4 / 6 entries (the register moves cost what the climbs cost); 896-triangle cone 9.15 -> 9.0 ms.
+#ifndef PBRT_BVH_RING
+#define PBRT_BVH_RING 0
+#endif
 template <bool ANY, typename NodeP, typename PrimP, typename IdP>
 DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
     const V3 inv = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)};
@@ -272,6 +280,10 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
     unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
     bool found = false;
     float best = tmax;
+#if PBRT_BVH_RING > 0
+    uint32_t ring[PBRT_BVH_RING];  // fully unrolled accesses: stays in VGPRs
+    uint32_t ring_n = 0, lvl = 0;  // valid entries, depth of `node` below the root
+#endif
     for (;;) {
         const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
         float t0, t1;
@@ -307,11 +319,36 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
         }
         const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
         if (i0 || i1) {
-            trail = (trail << 1) | ((i0 && i1) ? 1ull : 0ull);
-            node = (i0 && i1) ? (t0 <= t1 ? c0 : c1) : (i0 ? c0 : c1);
+            const bool both = i0 && i1;
+            const bool near0 = both ? (t0 <= t1) : i0;
+            trail = (trail << 1) | (both ? 1ull : 0ull);
+#if PBRT_BVH_RING > 0
+            ++lvl;
+            if (both) {  // defer the far child
+#pragma unroll
+                for (int k = PBRT_BVH_RING - 1; k > 0; --k) ring[k] = ring[k - 1];
+                ring[0] = (near0 ? c1 : c0) | (lvl << 24);
+                ring_n = min(ring_n + 1u, (uint32_t)PBRT_BVH_RING);
+            }
+#endif
+            node = near0 ? c0 : c1;
             continue;
         }
-        // pop: climb until a level with a pending sibling
+        // pop
+#if PBRT_BVH_RING > 0
+        if (ring_n > 0) {  // the newest deferred child is the pending sibling nearest above (pushes and pops are LIFO)
+            const uint32_t e = ring[0];
+#pragma unroll
+            for (int k = 0; k + 1 < PBRT_BVH_RING; ++k) ring[k] = ring[k + 1];
+            --ring_n;
+            const uint32_t l = e >> 24;
+            trail = (trail >> (lvl - l)) ^ 1ull;
+            lvl = l;
+            node = e & 0x00ffffffu;
+            continue;
+        }
+#endif
+        // climb until a level with a pending sibling
         bool done = false;
         while ((trail & 1ull) == 0ull) {
             if (trail == 0ull) {
@@ -320,6 +357,9 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
             }
             trail >>= 1;
             node = nodes[node].parent;
+#if PBRT_BVH_RING > 0
+            --lvl;
+#endif
         }
         if (done) break;
         const uint32_t p = nodes[node].parent;

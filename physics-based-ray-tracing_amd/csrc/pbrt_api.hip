@@ -292,9 +292,10 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);
-        if (bvh.max_depth > 60) {
+        if (bvh.max_depth > 60 || bvh.nodes.size() >= (1u << 24)) {  // 64-bit trail; ring entries: node | level << 24
             pbrt_scene_destroy(s);
-            return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", bvh.max_depth);
+            return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u / %zu nodes exceed the traversal state", bvh.max_depth,
+                           bvh.nodes.size());
         }
         std::vector<pbrt_prim> ordered(d->n_prims);
         for (uint32_t k = 0; k < d->n_prims; ++k) ordered[k] = d->prims[bvh.order[k]];

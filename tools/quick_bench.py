@@ -25,3 +25,8 @@ if "ALL" in os.environ:
     for i in range(2):
         ui._acquire(us, ui.quirks, paths_per_ray=65536); st = mi.default_context().stats()
     print(f"us_sphere_box 5x64x65536 paths: kernel {st['kernel_ms']:.2f} ms = {st['samples']/st['kernel_ms']/1e3:.0f} Mpaths/s segs/path {st['segments']/st['samples']:.2f}", flush=True)
+    us = mi.load_file(S + 'us_cone_box.xml', tessellate="true")
+    ui = us.integrator()
+    for i in range(2):
+        ui._acquire(us, ui.quirks, paths_per_ray=65536); st = mi.default_context().stats()
+    print(f"us_cone_box (896 triangles) 5x64x65536 paths: kernel {st['kernel_ms']:.2f} ms = {st['samples']/st['kernel_ms']/1e3:.0f} Mpaths/s", flush=True)

@@ -24,3 +24,9 @@ buf, tx = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 0, 32)
 nz = np.argwhere(buf != 0)
 np.savez_compressed(os.path.join(HERE, "us_plate_ppr32_seed0.npz"), index=nz.astype(np.int32), value=buf[buf != 0], tx=tx)
 print("golden images written")
+us = mi.load_file(scene_path("us_cone_box.xml"))          # analytic cone phantom
+ui = us.integrator()
+buf, tx = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 0, 8)
+nz = np.argwhere(buf != 0)
+np.savez_compressed(os.path.join(HERE, "us_cone_box_ppr8_seed0.npz"), index=nz.astype(np.int32), value=buf[buf != 0], tx=tx)
+print("cone phantom written:", len(nz), "non-zero bins")

@@ -42,9 +42,10 @@ def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed, kw):
     assert st["samples"] == ui.n_angles * ui.n_elements * ppr and ui.ray_count == st["segments"] > 0
 
 
-def test_golden_channel_buffer(mi):
-    g = np.load(os.path.join(GOLDEN, "us_plate_ppr32_seed0.npz"))
-    sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=32, seed=0)
+@pytest.mark.parametrize("scene,ppr,name", [("us_plate.xml", 32, "us_plate_ppr32_seed0.npz"), ("us_cone_box.xml", 8, "us_cone_box_ppr8_seed0.npz")])
+def test_golden_channel_buffer(mi, scene, ppr, name):
+    g = np.load(os.path.join(GOLDEN, name))
+    sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=0)
     ui = sc.integrator()
     ui.simulate_acquisition_parallel(sc)
     ref = np.zeros_like(ui.channel_buf)

@@ -357,6 +357,14 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     // shading tables -> LDS, behind the state loads so that the two memory round trips overlap
     if (ACCEL == ACCEL_K_BRUTE && !FIRST && !PERWAVE && it0 == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
     if (alive) {
+#ifdef PBRT_PROBE_EXTRA_VALU  // diagnostic builds only: N dependent full-rate VALU instructions per live wave-bounce
+        {
+            float probe = o.x;
+#pragma unroll
+            for (int k = 0; k < PBRT_PROBE_EXTRA_VALU; ++k) asm volatile("v_add_f32 %0, %0, %0" : "+v"(probe));
+            if (probe == 12345.678f) o.x = probe;  // never true; keeps the chain alive
+        }
+#endif
         if (!FIRST) path_key(a, home, &ka, &kb, &px, &py);
         const uint32_t depth = a.depth;
         const uint32_t nE = a.sc.n_emitters;

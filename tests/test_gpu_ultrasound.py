@@ -203,3 +203,35 @@ def test_fused_bounces_change_nothing(mi, ob, capi, case):
         assert st_f["live"][1] > 1000 and st_f["live"][2] > 100 and st_f["live"][3] > 10
         ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), 9, 300)
         check(fused.reshape(ref.shape), ref)
+
+
+def test_exact_normal_incidence_is_nan_as_in_the_reference(mi, ob):
+    """under the reference's literal arithmetic the 0-degree plane wave on a plate facing the probe
+    exactly (normal = -z) makes _ggx_sample normalise a zero vector (CustomBSDF.py:32-58) -- NaN echoes, the same bins
+    in the oracle and on the GPU; the intent arithmetic (quirks = 0) has no such case."""
+    T = mi.ScalarTransform4f
+
+    def scene(quirks):
+        return mi.load_dict({
+            "type": "scene",
+            "integrator": {"type": "ultrasound_integrator", "max_depth": 4, "sampling_rate": 40e6, "frequency": 4e6, "sound_speed": 1500,
+                           "attenuation": 0.1, "main_beam_angle": 20, "cutoff_angle": 35, "n_elements": 32, "pitch": 2e-4,
+                           "time_samples": 4000, "angles": [-5.0, 0.0, 5.0], "paths_per_ray": 50, "seed": 9,
+                           **({} if quirks is None else {"quirks": quirks})},
+            "sensor": {"type": "ultrasound_sensor", "to_world": T().look_at([0, 0, 0], [0, 0, 0.03], [0, 1, 0])},
+            "p": {"type": "rectangle", "to_world": T().translate([0, 0, 0.015]) @ T().rotate([1, 0, 0], 180) @ T().scale([0.03, 0.03, 1]),
+                  "bsdf": {"type": "ultrasound_bsdf", "impedance": 7.8, "roughness": 0.9}}})
+
+    sc = scene(None)
+    ui = sc.integrator()
+    got = ui._acquire(sc, ui.quirks).reshape(3, 32, 4000)
+    ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), 9, 50)
+    nan = np.isnan(ref)
+    assert nan.sum() > 100 and np.array_equal(np.isnan(got), nan) and not nan[[0, 2]].any()      # the 0-degree angle only
+    assert np.array_equal((got != 0) & ~nan, (ref != 0) & ~nan)
+    assert rel_l2(np.where(nan, 0, got), np.where(nan, 0, ref)) <= TOL_REL_L2
+    sc = scene(0)
+    ui = sc.integrator()
+    got = ui._acquire(sc, ui.quirks).reshape(3, 32, 4000)
+    ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), 9, 50)
+    check(got, ref)

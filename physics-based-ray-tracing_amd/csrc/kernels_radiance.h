@@ -114,6 +114,7 @@ struct RadArgs {
     // key mode 0 (render): home -> (region pixel, local sample)
     uint32_t key_mode;
     uint32_t rx0, ry0, rw, npix_r, s_first, film_w, film_h;
+    uint32_t tile_rows;  // rows of the region in 8-row bands (region_index); 0 for the brute-force kernels
     FastDiv div_npix, div_rw;  // exact home / npix_r and pr / rw without the 20-instruction variable udiv
     // key mode 1 (Integrator.sample on caller rays): key = (index_offset + home, sample_index)
     uint32_t index_offset, sample_index;
@@ -140,10 +141,31 @@ DEV void bst(Rsrc r, uint32_t voff, uint32_t soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
 }
 
+// Pixel order inside the rendered region (index k of a pixel = its slot within one sample's block of `Lhome` and
+// of the first-bounce state).  BVH kernels (TILED): the region is cut into bands of 8 rows and a band is walked
+// column by column, so the 64 consecutive paths of a wave are an 8 x 8 pixel tile, not a 64 x 1 strip -- their
+// primary rays visit fewer distinct nodes (every lane of a wave pays for the union).  The rh % 8 rows below the last
+// full band keep the row-major order; tile_rows = rh & ~7 (0: plain row-major everywhere, brute-force kernels --
+// uniform primitive loops gain nothing from coherence and the extra index arithmetic costs them 0.5 %).
+DEV uint32_t region_index(uint32_t xx, uint32_t yy, uint32_t rw, uint32_t tile_rows) {
+    return yy < tile_rows ? (yy >> 3) * (8u * rw) + (xx << 3) + (yy & 7u) : yy * rw + xx;
+}
+
+template <bool TILED>
 DEV void path_key(const RadArgs &a, uint32_t home, uint32_t *ka, uint32_t *kb, uint32_t *px, uint32_t *py) {
     if (a.key_mode == 0) {
         uint32_t sl = udiv_fast(home, a.div_npix), pr = home - sl * a.npix_r;
-        uint32_t ry = udiv_fast(pr, a.div_rw), rx = pr - ry * a.rw;
+        uint32_t rx, ry;
+        if (TILED) {  // inverse of region_index: one division either way
+            const bool tiled = pr < a.tile_rows * a.rw;
+            const uint32_t num = tiled ? pr >> 3 : pr;
+            const uint32_t q = udiv_fast(num, a.div_rw);
+            rx = num - q * a.rw;
+            ry = tiled ? (q << 3) + (pr & 7u) : q;
+        } else {
+            ry = udiv_fast(pr, a.div_rw);
+            rx = pr - ry * a.rw;
+        }
         *px = a.rx0 + rx;
         *py = a.ry0 + ry;
         *ka = *py * a.film_w + *px;
@@ -239,6 +261,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const uint32_t seg = blockIdx.x;  // region index
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REGION = rad_region_segs(ACCEL) * SEG;
+    constexpr bool TILED = ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS;  // 8 x 8 pixel tiles per wave (path_key)
     constexpr bool DYN = rad_dynamic(ACCEL);                  // chunk queue + slot reservation in LDS (BVH kernels)
     constexpr bool WP = rad_wave_private(ACCEL) && !DYN;      // fixed per-wave shares (diagnostic fallback)
     constexpr bool PERWAVE = WP || DYN;                       // the waves walk 64-path chunks on their own
@@ -332,7 +355,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     if (alive) {
         if (FIRST) {
             home = slot;
-            path_key(a, home, &ka, &kb, &px, &py);
+            path_key<TILED>(a, home, &ka, &kb, &px, &py);
             F4 uj = rng4(ka, kb, 0, a.seed);
             float fx = (float)px + uj.x, fy = (float)py + uj.y;
             camera_ray(a.cam, fx / (float)a.film_w, fy / (float)a.film_h, &o, &d, &tmax);
@@ -365,7 +388,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
             if (probe == 12345.678f) o.x = probe;  // never true; keeps the chain alive
         }
 #endif
-        if (!FIRST) path_key(a, home, &ka, &kb, &px, &py);
+        if (!FIRST) path_key<TILED>(a, home, &ka, &kb, &px, &py);
         const uint32_t depth = a.depth;
         const uint32_t nE = a.sc.n_emitters;
         Hit h;
@@ -568,6 +591,7 @@ struct FilmArgs {
     uint32_t cx0, cy0, cw, ch;     // crop
     uint32_t rx0, ry0, rw, rh;     // rendered region (crop + halo, clipped to the film)
     uint32_t npix_r, s_first, s_count, film_w, film_h, filter, seed;
+    uint32_t tile_rows;            // pixel order of Lhome (region_index)
 };
 
 DEV float filter_1d(uint32_t f, float x) {
@@ -598,7 +622,7 @@ __global__ __launch_bounds__(256) void k_film_accum(const FilmArgs a) {
                     w = filter_1d(a.filter, ccx - px) * filter_1d(a.filter, ccy - py);
                 }
                 if (w > 0.0f) {
-                    const uint32_t k = (uint32_t)(ny - (int)a.ry0) * a.rw + (uint32_t)(nx - (int)a.rx0);
+                    const uint32_t k = region_index((uint32_t)(nx - (int)a.rx0), (uint32_t)(ny - (int)a.ry0), a.rw, a.tile_rows);
                     const float4 Lk = Ls[k];
                     ar = fma_(w, Lk.x, ar);
                     ag = fma_(w, Lk.y, ag);
@@ -662,7 +686,7 @@ __global__ __launch_bounds__(FILM_TILE *FILM_TILE) void k_film_accum_tiled(const
         st_in[j] = i < TW * TW;
         st_valid[j] = st_in[j] && nx >= (int)a.rx0 && ny >= (int)a.ry0 && nx < (int)(a.rx0 + a.rw) && ny < (int)(a.ry0 + a.rh);
         st_key[j] = (uint32_t)ny * a.film_w + (uint32_t)nx;
-        st_k[j] = st_valid[j] ? (uint32_t)(ny - (int)a.ry0) * a.rw + (uint32_t)(nx - (int)a.rx0) : 0u;
+        st_k[j] = st_valid[j] ? region_index((uint32_t)(nx - (int)a.rx0), (uint32_t)(ny - (int)a.ry0), a.rw, a.tile_rows) : 0u;
         st_x[j] = (float)nx;
         st_y[j] = (float)ny;
     }

@@ -47,6 +47,16 @@ inline bool cone_world_frame(const pbrt_prim &P, double c[3], double a[3], doubl
     return true;
 }
 
+// SAH parameters (A/B-able): cost of one node step relative to one primitive test, and the largest leaf.
+// Measured on MI355X (ring 1024^2 x 64 spp / 896-triangle cone phantom): 0.25 / 0.5 / 1 / 2 at <= 4 per leaf:
+// 21.95 / 22.05 / 22.10 / 24.13 ms; leaves of <= 2 / 6 / 8: 22.07 / 22.13 / 24.04 ms -- flat around the defaults.
+#ifndef BVH_CTRAV
+#define BVH_CTRAV 0.5f
+#endif
+#ifndef BVH_MAX_LEAF
+#define BVH_MAX_LEAF 4
+#endif
+
 namespace bvh_detail {
 
 struct Box {
@@ -118,7 +128,7 @@ struct Builder {
         const int NB = 16;
         int best_axis = -1, best_split = -1;
         float best_cost = (float)count * bb.area();  // leaf cost
-        if (count > 4) best_cost = INFINITY;         // force a split above the leaf limit
+        if (count > BVH_MAX_LEAF) best_cost = INFINITY;  // force a split above the leaf limit
         for (int axis = 0; axis < 3 && count > 1; ++axis) {
             float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
             if (!(ext > 0)) continue;
@@ -150,7 +160,7 @@ struct Builder {
             }
             for (int b = 0; b + 1 < NB; ++b) {
                 if (lc[b] == 0 || rc[b + 1] == 0) continue;
-                float cost = 0.5f * bb.area() + la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+                float cost = BVH_CTRAV * bb.area() + la[b] * lc[b] + ra[b + 1] * rc[b + 1];
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_axis = axis;

@@ -73,3 +73,35 @@ def test_invalid_ultrasound_and_leaf_arguments(mi, capi):
         mi.apply_pulse(np.zeros((2, 100), np.float32), 50e6, 3e6, -1.0)
     with pytest.raises(RuntimeError):
         mi.log_compress(np.ones(4, np.float32), dynamic_range=0.0)
+
+
+def test_scenes_and_contexts_release_their_device_memory(mi):
+    """create / render / destroy in a loop: the free device memory (hipMemGetInfo of the runtime the library itself is
+    linked to) does not shrink -- scene buffers, BVH uploads and the context's work buffers are all released"""
+    import ctypes
+    import gc
+
+    from conftest import scene_path
+
+    hip = ctypes.CDLL("libamdhip64.so")        # already loaded by libpbrt_hip.so: the same runtime instance
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipDeviceSynchronize() == 0 and hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    def cycle(n):
+        for i in range(n):
+            extra = mi.Context()               # a second context next to the default one: created and closed
+            for scene, kw in (("cbox.xml", dict(res=32, spp=2)), ("testring.xml", dict(res=32, spp=1))):
+                sc = mi.load_file(scene_path(scene), **kw)
+                mi.render(sc, seed=i)          # uploads the scene (LDS-BVH image for the ring) and renders
+                del sc                         # DeviceScene.__del__ -> pbrt_scene_destroy
+            extra.close()
+            gc.collect()
+
+    cycle(3)                                   # warm-up: allocator pools, code objects
+    free0 = free_bytes()
+    cycle(25)
+    free1 = free_bytes()
+    assert free0 - free1 < 64 << 20            # 50 scenes with a 100 KB - 30 MB footprint each would show

@@ -107,6 +107,26 @@ def test_crop_sample_offset_raw_and_pass_size(mi, ob):
     assert np.array_equal(rr[..., :3] * (np.float32(1.0) / rr[..., 3:4]), full)      # resolve multiplies by 1/w
 
 
+@pytest.mark.parametrize("filt", ["tent", "box", "gaussian"])
+def test_bvh_scene_crops_and_passes_with_tiled_pixel_order(mi, ob, filt):
+    """BVH kernels walk the rendered region in 8-row bands, column by column (region_index): regions whose height is
+    not a multiple of 8 keep their last rows in row-major order, and the film gather must use the same index --
+    crops of every alignment equal the slice of the full film, and the full film equals the oracle's"""
+    sc = mi.load_file(scene_path("testring.xml"), res=45, spp=3)
+    sc.sensors()[0].film().rfilter = mi.ReconstructionFilter(mi.Properties(filt))
+    integ = sc.integrator()
+    full = integ.render(sc, seed=6, spp=3)
+    ref, _ = oracle_render(ob, sc, 6, 3)
+    if filt == "gaussian":   # expf in the filter weight: ocml vs libm, last ulp
+        assert np.allclose(full, ref, rtol=1e-5, atol=1e-7) and full.mean() > 0
+    else:
+        assert np.array_equal(full, ref) and full.mean() > 0
+    for crop in ((0, 0, 45, 45), (3, 5, 29, 13), (0, 37, 45, 8), (10, 0, 7, 7), (40, 1, 5, 44), (0, 8, 45, 16), (11, 19, 1, 1)):
+        x, y, w, h = crop
+        assert np.array_equal(integ.render(sc, seed=6, spp=3, crop=crop), full[y:y + h, x:x + w]), crop
+    assert np.array_equal(integ.render(sc, seed=6, spp=3, pass_paths=45 * 45 + 17), full)       # passes of 1 sample + change
+
+
 def test_non_square_film_and_camera(mi, ob):
     sc = mi.load_dict({
         "type": "scene", "integrator": {"type": "path", "max_depth": 4},

@@ -31,6 +31,7 @@ struct UsArgs {
     uint32_t lds_bytes;
     uint32_t stat_stride;
     uint32_t fuse;  // bounces a.depth .. max_depth - 1 in this launch (k_us_bounce<false>)
+    FastDiv div_ppr, div_ne;  // exact home / ppr_pass and ray_id / n_elements without the 20-instruction variable udiv
     // First-bounce tables (k_us_first): the primary ray of an (angle, element) pair is deterministic
     // (CustomIntegrator.py:270-273), so all P paths of a ray share the first hit, and the occlusion of the ray to a
     // receive element, the directivity weight, the echo time and its carrier depend on (ray, element) only.  Computed
@@ -141,11 +142,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     float amp, atten, tof, geo_len;
     uint32_t home = slot;
     if (alive) {
+#ifdef PBRT_PROBE_EXTRA_VALU  // diagnostic builds only (see k_bounce)
+        {
+            float probe = __uint_as_float(slot);
+#pragma unroll
+            for (int kk = 0; kk < PBRT_PROBE_EXTRA_VALU; ++kk) asm volatile("v_add_f32 %0, %0, %0" : "+v"(probe));
+            if (probe == 12345.678f) home = 0;  // never true; keeps the chain alive
+        }
+#endif
         uint32_t ray_id, k;
         if (first) {
-            ray_id = home / a.ppr_pass;
+            ray_id = udiv_fast(home, a.div_ppr);
             k = a.path_first + (home - ray_id * a.ppr_pass);
-            const uint32_t ang = ray_id / NE, el = ray_id - ang * NE;
+            const uint32_t ang = udiv_fast(ray_id, a.div_ne), el = ray_id - ang * NE;
             o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));           // :270,273
             d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);         // :271,273
             amp = 1.0f;
@@ -161,10 +170,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             tof = s[8 * cap];
             geo_len = s[9 * cap];
             home = __float_as_uint(s[10 * cap]);
-            ray_id = home / a.ppr_pass;
+            ray_id = udiv_fast(home, a.div_ppr);
             k = a.path_first + (home - ray_id * a.ppr_pass);
         }
-        const uint32_t ang = ray_id / NE;
+        const uint32_t ang = udiv_fast(ray_id, a.div_ne);
         const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         Hit h;
         bool hit;

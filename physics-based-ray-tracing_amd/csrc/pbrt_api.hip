@@ -822,6 +822,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     a.seed = seed;
     a.lds_bytes = s->lds_bytes;
     a.fuse = (p->quirks & PBRT_USQ_NO_FUSED_BOUNCES) ? 0u : 1u;
+    a.div_ne = make_fastdiv(NE);
+    for (uint32_t n : {0u, 1u, NE - 1, NE, NE + 1, n_rays - 1, n_rays}) NEED(c, udiv_fast_host(n, a.div_ne) == n / NE);
     // first-bounce tables (kernels_us.h k_us_first): worth it once a ray has more paths than receive elements
     if (ppr >= NE && !(p->quirks & PBRT_USQ_NO_FIRST_TABLES)) {
         float4 *fh = (float4 *)c->buf("us_first_hit", (size_t)n_rays * 16);
@@ -842,6 +844,9 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     for (uint32_t k0 = 0; k0 < ppr; k0 += ppr_pass, ++passes) {
         const uint32_t kc = std::min(ppr_pass, ppr - k0);
         a.ppr_pass = kc;
+        a.div_ppr = make_fastdiv(kc);
+        for (uint32_t n : {0u, 1u, kc - 1, kc, kc + 1, n_rays * kc - 1, n_rays * kc, 0xfffffbffu})
+            NEED(c, udiv_fast_host(n, a.div_ppr) == n / kc);
         a.path_first = path_offset + k0;
         a.n_paths = n_rays * kc;
         const uint32_t nseg_pass = div_up(a.n_paths, REGION);

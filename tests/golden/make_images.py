@@ -18,6 +18,8 @@ sc = mi.load_file(scene_path("cbox.xml"), res=32, spp=8)
 np.save(os.path.join(HERE, "cbox_32x32_spp8_seed0.npy"), oracle_render(ob, sc, 0, 8)[0])
 sc = mi.load_file(scene_path("simple.xml"), res=64, spp=4)
 np.save(os.path.join(HERE, "simple_64x64_spp4_seed0.npy"), oracle_render(ob, sc, 0, 4)[0])
+sc = mi.load_file(scene_path("cone_room.xml"), res=32, spp=8)      # analytic cones in radiance mode (diffuse, glass)
+np.save(os.path.join(HERE, "cone_room_32x32_spp8_seed0.npy"), oracle_render(ob, sc, 0, 8)[0])
 us = mi.load_file(scene_path("us_plate.xml"))
 ui = us.integrator()
 buf, tx = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 0, 32)

@@ -10,7 +10,8 @@ from conftest import GOLDEN, oracle_render, scene_path
 
 
 @pytest.mark.parametrize("scene,kw,spp,name", [("cbox.xml", dict(res=32, spp=8), 8, "cbox_32x32_spp8_seed0.npy"),
-                                               ("simple.xml", dict(res=64, spp=4), 4, "simple_64x64_spp4_seed0.npy")])
+                                               ("simple.xml", dict(res=64, spp=4), 4, "simple_64x64_spp4_seed0.npy"),
+                                               ("cone_room.xml", dict(res=32, spp=8), 8, "cone_room_32x32_spp8_seed0.npy")])
 def test_oracle_reproduces_golden_film(mi, ob, scene, kw, spp, name):
     g = np.load(os.path.join(GOLDEN, name))
     img, _ = oracle_render(ob, mi.load_file(scene_path(scene), **kw), 0, spp)

@@ -33,9 +33,12 @@ def test_cbox_matches_oracle(mi, ob, res, spp, seed):
     assert gst["samples"] == res * res * spp
 
 
-def test_cbox_golden_image(mi):
-    g = np.load(os.path.join(GOLDEN, "cbox_32x32_spp8_seed0.npy"))
-    sc = mi.load_file(scene_path("cbox.xml"), res=32, spp=8)
+@pytest.mark.parametrize("scene,name", [("cbox.xml", "cbox_32x32_spp8_seed0.npy"), ("cone_room.xml", "cone_room_32x32_spp8_seed0.npy")])
+def test_golden_images(mi, scene, name):
+    """committed oracle films: the Cornell box (brute-force kernels), and a room with a diffuse and a glass analytic cone
+    and a mirror sphere (the brute-force variant that carries the cone code)"""
+    g = np.load(os.path.join(GOLDEN, name))
+    sc = mi.load_file(scene_path(scene), res=32, spp=8)
     img = mi.render(sc, seed=0)
     assert rmse(img, g) <= TOL_L2 and np.array_equal(img, g)
 

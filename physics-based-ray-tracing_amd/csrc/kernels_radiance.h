@@ -59,7 +59,9 @@ __host__ __device__ constexpr uint32_t seg_threads(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH : SEG_BRUTE;
 }
 __host__ __device__ constexpr uint32_t seg_waves_per_eu(int accel) {
-    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH / 256 : SEG_WAVES_PER_EU;
+    // _BIG (tables in global memory, cone code): 4 spilled VGPRs at the 64-register budget, and the budget itself is
+    // worth nothing to these kernels (cbox at 4 waves per SIMD: 8.69 against 8.77 ms), so it gets 128
+    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH / 256 : (accel == ACCEL_K_BRUTE_BIG ? 4 : SEG_WAVES_PER_EU);
 }
 // BVH kernels compact per WAVE: every wave owns REGION / (SEG / 64) slots of its workgroup's region, walks its own
 // live prefix 64 paths at a time and packs its survivors with ballot + mbcnt alone -- no barrier after the scene is

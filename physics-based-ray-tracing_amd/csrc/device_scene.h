@@ -38,6 +38,10 @@ struct DevScene {
     // mode, pbrt_ray_test) always walk the full list.
     const pbrt_prim *occ_prims;
     uint32_t n_occ;
+#ifdef PBRT_BRUTE_PAIRS
+    const struct PairItem *pair_items;  // ACCEL_K_BRUTE: sc.prims as pairs of planar primitives (brute_closest_pairs)
+    uint32_t n_pair_items;
+#endif
     uint32_t n_prims, n_nodes, n_emitters, n_mats, n_light_prims;
 };
 
@@ -250,6 +254,111 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     }
     return found;
 }
+
+// ---- closest hit, two planar primitives per iteration (ACCEL_K_BRUTE): diagnostic build -DPBRT_BRUTE_PAIRS ------
+// Measured: bit-identical film, but 8.77 against 8.33 ms on cbox -- the 27 packed instructions replace 48, yet the
+// compare / select / ranking part of each primitive grows (the `found` flag moves into a VGPR, 20-26 SGPRs of the
+// 2 x 32-dword records spill), 85 against 92 VALU per pair in the end, and the 128-byte records double the scalar
+// loads.  Kept as a build switch; the shipped library uses brute_intersect.
+#ifdef PBRT_BRUTE_PAIRS
+// The kernel is instruction-issue bound and the Moeller-Trumbore set-up is 27 multiply-adds per primitive.  The host
+// interleaves the v0 / e1 / e2 of two consecutive planar primitives into one 128-byte record (pbrt_api.hip
+// build_pair_items), so that every one of those operations is ONE packed instruction for both (v_pk_mul_f32 /
+// v_pk_fma_f32 / v_pk_add_f32, the record in SGPR pairs): 27 instead of 48 VALU per pair.  Packed f32 is IEEE per
+// component and the operation order is that of cross() / dot() above, candidates are ranked A before B, so the
+// result is the same bit for bit as brute_intersect<false>.  Spheres (kind 1) take the scalar path.
+typedef float __attribute__((ext_vector_type(2))) f2;
+struct PairItem {         // 32 dwords, wave-uniform
+    uint32_t dw[32];      // kind 0: dw[2k], dw[2k+1] = g[k] of A, B for k = 0..8 | kind 1: dw[0..15] = the pbrt_prim
+};                        // dw[18] typeA, dw[19] typeB (0xffffffff: none), dw[20] kind, dw[21] index of A in sc.prims
+DEV PairItem load_pair_uniform(const PairItem *p) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    typedef const u32x4 __attribute__((address_space(4))) *cptr;
+    struct Raw {
+        u32x4 q[8];
+    };
+    static_assert(sizeof(Raw) == sizeof(PairItem), "PairItem is 32 dwords");
+    cptr q = (cptr)(uintptr_t)p;
+    Raw r = {{q[0], q[1], q[2], q[3], q[4], q[5], q[6], q[7]}};
+    return __builtin_bit_cast(PairItem, r);
+}
+DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+DEV f2 pk_splat(float x) { return {x, x}; }
+
+DEV bool brute_closest_pairs(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
+    bool found = false;
+    float bn = 0.0f, bd = 1.0f, bu = 0.0f, bv = 0.0f;
+    uint32_t bp = 0xffffffffu;
+    const uint32_t n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)sc.n_pair_items);
+    if (n_items == 0) return false;
+    auto rank = [&](bool ok, float num, float den, float us, float vs, uint32_t idx) {
+        const bool better = ok & (!found | (num * bd < bn * den));
+        bn = better ? num : bn;
+        bd = better ? den : bd;
+        bu = better ? us : bu;
+        bv = better ? vs : bv;
+        bp = better ? idx : bp;
+        found = found | better;
+    };
+    auto planar = [&](float det, float us, float vs, float ts, uint32_t type, uint32_t idx) {
+        const bool neg = det < 0.0f;
+        det = neg ? -det : det;
+        us = neg ? -us : us;
+        vs = neg ? -vs : vs;
+        ts = neg ? -ts : ts;
+        bool ok = (det > 0.0f) & (fminf(fminf(us, vs), ts) >= 0.0f) & (ts <= tmax * det);
+        if (type == PBRT_PRIM_TRIANGLE)
+            ok = ok & (us + vs <= det);
+        else
+            ok = ok & (fmaxf(us, vs) <= det);
+        rank(ok, ts, det, us, vs, idx);
+    };
+    const f2 dx = pk_splat(d.x), dy = pk_splat(d.y), dz = pk_splat(d.z);
+    const f2 ox = pk_splat(o.x), oy = pk_splat(o.y), oz = pk_splat(o.z);
+    PairItem nxt = load_pair_uniform(sc.pair_items);
+    for (uint32_t i = 0; i < n_items; ++i) {
+        const PairItem R = nxt;
+        nxt = load_pair_uniform(sc.pair_items + min(i + 1, n_items - 1));
+        const uint32_t idA = R.dw[21];
+        if (R.dw[20] != 0u) {  // one primitive of any type: the scalar test
+            struct Half {
+                uint32_t w[16];
+            };
+            Half hw;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) hw.w[k] = R.dw[k];
+            const pbrt_prim P = __builtin_bit_cast(pbrt_prim, hw);
+            __builtin_assume(P.type == PBRT_PRIM_SPHERE);  // planar primitives travel in pairs, cones never reach this variant
+            float t, u, v;
+            const bool ok = prim_hit(P, o, d, tmax, &t, &u, &v);
+            rank(ok, t, 1.0f, u, 0.0f, idA);
+            continue;
+        }
+        auto g2 = [&](int k) -> f2 { return {__uint_as_float(R.dw[2 * k]), __uint_as_float(R.dw[2 * k + 1])}; };
+        const f2 v0x = g2(0), v0y = g2(1), v0z = g2(2), e1x = g2(3), e1y = g2(4), e1z = g2(5), e2x = g2(6), e2y = g2(7), e2z = g2(8);
+        // pvec = cross(d, e2)
+        const f2 px = pk_fma(dy, e2z, -(dz * e2y)), py = pk_fma(dz, e2x, -(dx * e2z)), pz = pk_fma(dx, e2y, -(dy * e2x));
+        const f2 det = pk_fma(e1x, px, pk_fma(e1y, py, e1z * pz));                    // dot(e1, pvec)
+        const f2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;                           // tvec = o - v0
+        // qvec = cross(tvec, e1)
+        const f2 qx = pk_fma(ty, e1z, -(tz * e1y)), qy = pk_fma(tz, e1x, -(tx * e1z)), qz = pk_fma(tx, e1y, -(ty * e1x));
+        const f2 us = pk_fma(tx, px, pk_fma(ty, py, tz * pz));                        // dot(tvec, pvec)
+        const f2 vs = pk_fma(dx, qx, pk_fma(dy, qy, dz * qz));                        // dot(d, qvec)
+        const f2 ts = pk_fma(e2x, qx, pk_fma(e2y, qy, e2z * qz));                     // dot(e2, qvec)
+        planar(det.x, us.x, vs.x, ts.x, R.dw[18], idA);
+        if (R.dw[19] != 0xffffffffu) planar(det.y, us.y, vs.y, ts.y, R.dw[19], idA + 1u);
+    }
+    if (found) {
+        float inv = 1.0f / bd;
+        h->t = bn * inv;
+        h->u = bu * inv;
+        h->v = bv * inv;
+        h->prim = bp;
+        h->slot = bp;
+    }
+    return found;
+}
+#endif  // PBRT_BRUTE_PAIRS
 
 // ---- BVH2 traversal without a stack; NodeP / PrimP / IdP are global or LDS pointers -------------
 // Box tests are conservative (boxes are padded at build time, reciprocal directions are approximate);

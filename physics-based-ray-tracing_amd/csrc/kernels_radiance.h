@@ -190,6 +190,9 @@ struct LdsScene {
 // scenes then only walk the primitives that can occlude such a segment (DevScene::occ_prims).
 template <int ACCEL, bool ANY, bool SEGMENT = false>
 DEV bool scene_intersect(const DevScene &sc, const LdsScene &ls, V3 o, V3 d, float tmax, Hit *h) {
+#ifdef PBRT_BRUTE_PAIRS
+    if (ACCEL == ACCEL_K_BRUTE && !ANY) return brute_closest_pairs(sc, o, d, tmax, h);
+#endif
     if (ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG)
         return brute_intersect<ANY, SEGMENT, ACCEL != ACCEL_K_BRUTE>(sc, o, d, tmax, h);
     if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(sc.nodes, sc.prims, sc.prim_ids, o, d, tmax, h);

@@ -107,6 +107,40 @@ static inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b
 // plane: it then sits on the boundary of the scene's convex hull and a segment whose end points are in the
 // hull cannot cross it.  Exact comparisons (>= 0 in f64 on the f32 data), so nearly-coplanar scenes just
 // keep their primitives.
+#ifdef PBRT_BRUTE_PAIRS
+// Consecutive planar primitives two by two, their v0 / e1 / e2 interleaved; everything else (spheres) on its own.
+static std::vector<PairItem> build_pair_items(const pbrt_prim *prims, uint32_t n) {
+    auto planar = [](const pbrt_prim &P) { return P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM; };
+    std::vector<PairItem> items;
+    for (uint32_t i = 0; i < n;) {
+        PairItem it;
+        std::memset(&it, 0, sizeof it);
+        it.dw[21] = i;
+        if (!planar(prims[i])) {
+            std::memcpy(it.dw, &prims[i], sizeof(pbrt_prim));
+            it.dw[18] = prims[i].type;
+            it.dw[19] = 0xffffffffu;
+            it.dw[20] = 1;
+            it.dw[21] = i;
+            i += 1;
+        } else {
+            const bool two = i + 1 < n && planar(prims[i + 1]);
+            const pbrt_prim &A = prims[i], &B = prims[two ? i + 1 : i];
+            for (int k = 0; k < 9; ++k) {
+                std::memcpy(&it.dw[2 * k], &A.g[k], 4);
+                std::memcpy(&it.dw[2 * k + 1], &B.g[k], 4);
+            }
+            it.dw[18] = A.type;
+            it.dw[19] = two ? B.type : 0xffffffffu;
+            it.dw[20] = 0;
+            i += two ? 2 : 1;
+        }
+        items.push_back(it);
+    }
+    return items;
+}
+#endif
+
 static std::vector<pbrt_prim> find_occluders(const pbrt_scene_desc *d) {
     std::vector<pbrt_prim> occ;
     for (uint32_t i = 0; i < d->n_prims; ++i) {
@@ -289,6 +323,13 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         std::vector<pbrt_prim> occ = find_occluders(d);
         UP(upload(s, occ.data(), occ.size(), &s->ds.occ_prims));
         s->ds.n_occ = (uint32_t)occ.size();
+#ifdef PBRT_BRUTE_PAIRS
+        if (s->accel_kernel == ACCEL_K_BRUTE) {  // pair records for brute_closest_pairs (device_scene.h)
+            std::vector<PairItem> items = build_pair_items(d->prims, d->n_prims);
+            UP(upload(s, items.data(), items.size(), &s->ds.pair_items));
+            s->ds.n_pair_items = (uint32_t)items.size();
+        }
+#endif
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);

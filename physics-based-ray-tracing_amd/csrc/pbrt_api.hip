@@ -810,7 +810,10 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     for (uint32_t e = 0; e < NE; ++e)
         ex[e] = (float)((double)p->pitch * ((double)(float)e - ((double)NE - 1.0) / 2.0));  // :248
 #ifndef US_PASS_PATHS
-#define US_PASS_PATHS (16u << 20)  // paths in flight per pass; config 3 (268 M paths): 8 / 16 / 32 / 64 Mi -> 13.1 / 12.7 / 13.0 / 13.2 ms
+// paths in flight per pass.  Config 3 (268 M paths), one launch per bounce: 8 / 16 / 32 / 64 Mi -> 13.1 / 12.7 / 13.0 /
+// 13.2 ms; with all bounces of a pass in one launch the survivors are re-read while still cached and smaller passes
+// win: 2 / 4 / 6 / 8 / 12 / 16 / 32 / 64 Mi -> 13.1 / 9.8 / 8.4 / 8.1 / 8.2 / 8.5 / 9.0 / 8.7 ms
+#define US_PASS_PATHS (8u << 20)
 #endif
     const uint64_t pass_paths = US_PASS_PATHS;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PBRT_ABI_VERSION 1
+#define PBRT_ABI_VERSION 2
 
 /* ---- error classes ------------------------------------------------------------------------ */
 #define PBRT_OK 0
@@ -296,12 +296,15 @@ int pbrt_ray_test(pbrt_scene *scene, uint32_t n, const float *o, const float *d,
  *  wi      [3][n] incident direction in the local shading frame (si.wi)
  *  n_geo   [3][n] world geometric normal (si.n)        -- read by ULTRA only
  *  n_sh    [3][n] world shading normal (si.sh_frame.n) -- read by ULTRA only
+ *  sh_s    [3][n] tangent of the shading frame (si.sh_frame.s, or the shape's dp_du: Mitsuba builds the frame as
+ *                 s = normalize(dp_du - n (n . dp_du)), t = n x s) -- read by ULTRA only, for bs.wo = si.to_local(chosen)
+ *                 (CustomBSDF.py:165); NULL: coordinate_system(n_sh)
  *  s1 [n], s2 [2][n] the uniform variates
  *  out: wo [3][n] local, pdf [n], weight [3][n] (ULTRA: amplitude in weight[0], rest equal),
  *       sampled [n]: 0 = reflection lobe, 1 = transmission lobe, 0xffffffff = invalid sample */
 int pbrt_bsdf_sample(pbrt_ctx *ctx, const pbrt_material *m, uint32_t quirks, uint32_t n, const float *wi,
-                     const float *n_geo, const float *n_sh, const float *s1, const float *s2, float *wo, float *pdf,
-                     float *weight, uint32_t *sampled);
+                     const float *n_geo, const float *n_sh, const float *sh_s, const float *s1, const float *s2, float *wo,
+                     float *pdf, float *weight, uint32_t *sampled);
 /* replaces: BSDF.eval / BSDF.pdf / BSDF.eval_pdf (CustomBSDF.py:177-184: constant 0 for ULTRA).
  * f [3][n] = bsdf value * cos(theta_o). */
 int pbrt_bsdf_eval_pdf(pbrt_ctx *ctx, const pbrt_material *m, uint32_t n, const float *wi, const float *wo, float *f,

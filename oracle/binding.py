@@ -139,18 +139,20 @@ class OracleScene:
             pass
 
 
-def bsdf_sample(material, quirks, wi, n_geo, n_sh, s1, s2):
+def bsdf_sample(material, quirks, wi, n_geo, n_sh, s1, s2, sh_s=None):
     wi = f32(np.asarray(wi).T)
     n = wi.shape[1]
     ng = f32(np.broadcast_to(np.asarray(n_geo, np.float32), (n, 3)).T)
     ns = f32(np.broadcast_to(np.asarray(n_sh, np.float32), (n, 3)).T)
+    ss = f32(np.broadcast_to(np.asarray(sh_s, np.float32), (n, 3)).T) if sh_s is not None else None
     s1 = f32(np.broadcast_to(s1, (n,)))
     s2 = f32(np.asarray(s2).T)
     wo, w = np.empty((3, n), np.float32), np.empty((3, n), np.float32)
     pdf = np.empty(n, np.float32)
     lobe = np.empty(n, np.uint32)
     _chk(lib().oracle_bsdf_sample(C.byref(material), C.c_uint32(quirks), C.c_uint32(n), _P(A(wi)), _P(A(ng)), _P(A(ns)),
-                                  _P(A(s1)), _P(A(s2)), _P(A(wo)), _P(A(pdf)), _P(A(w)), _P(A(lobe))), "oracle_bsdf_sample")
+                                  _P(A(ss) if ss is not None else None), _P(A(s1)), _P(A(s2)), _P(A(wo)), _P(A(pdf)), _P(A(w)),
+                                  _P(A(lobe))), "oracle_bsdf_sample")
     return wo.T.copy(), pdf, w.T.copy(), lobe
 
 

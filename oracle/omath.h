@@ -133,6 +133,20 @@ static inline Frame make_frame(V3 n) {
     f.n = n;
     return f;
 }
+// Mitsuba SurfaceInteraction::initialize_sh_frame(): the shading frame of an intersection is NOT coordinate_system(n)
+// but s = normalize(dp_du - n (n . dp_du)), t = n x s, with the shape's dp_du (si.wi = sh_frame.to_local(-ray.d),
+// read at CustomBSDF.py:90; si.to_local / si.to_world at CustomBSDF.py:165, CustomIntegrator.py:358).
+// A zero dp_du (no parameterisation) falls back to coordinate_system(n).
+static inline Frame make_sh_frame(V3 n, V3 dp_du) {
+    V3 s = madd(n, -dot(n, dp_du), dp_du);
+    float l2 = dot(s, s);
+    if (!(l2 > 0.0f)) return make_frame(n);
+    Frame f;
+    f.s = s * (1.0f / sqrtf(l2));
+    f.t = cross(n, f.s);
+    f.n = n;
+    return f;
+}
 static inline V3 to_local(const Frame &f, V3 v) { return {dot(v, f.s), dot(v, f.t), dot(v, f.n)}; }
 static inline V3 to_world(const Frame &f, V3 v) {
     return {fmaf(f.s.x, v.x, fmaf(f.t.x, v.y, f.n.x * v.z)), fmaf(f.s.y, v.x, fmaf(f.t.y, v.y, f.n.y * v.z)),

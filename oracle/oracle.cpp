@@ -506,6 +506,16 @@ inline SI make_si(const Scene &sc, V3 o, V3 d, const Hit &h) {
     return si;
 }
 
+// dp_du of the interaction, input of Mitsuba's shading frame (omath.h make_sh_frame): first edge of a triangle /
+// parallelogram (Mesh without texture coordinates: p1 - p0; `rectangle`: to_world * (2,0,0)), 2 pi (-y, x, 0) about the
+// centre of a sphere (object axes taken parallel to the world's), none for the [DEFINE] cone (-> coordinate_system(n))
+inline V3 si_dp_du(const SI &si) {
+    const pbrt_prim &P = *si.prim;
+    if (P.type == PBRT_PRIM_SPHERE) return {-(si.p.y - P.g[1]), si.p.x - P.g[0], 0.0f};
+    if (P.type == PBRT_PRIM_CONE) return {0.0f, 0.0f, 0.0f};
+    return g3(P, 3);
+}
+
 // ------------------------------------------------------------------------------------------------
 // BSDFs, radiance mode (Mitsuba diffuse / conductor / dielectric)
 // ------------------------------------------------------------------------------------------------
@@ -519,8 +529,8 @@ struct BSample {
     uint32_t lobe;  // 0 reflection, 1 transmission
 };
 
-void ultra_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, float s1, float s2x, float s2y,
-                  V3 *wo, float *pdf, float *amp, uint32_t *lobe);
+void ultra_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, const Frame &shf, float s1, float s2x,
+                  float s2y, V3 *wo, float *pdf, float *amp, uint32_t *lobe);
 
 inline bool mat_smooth(const pbrt_material &m) { return m.type == PBRT_MAT_DIFFUSE; }
 
@@ -535,8 +545,9 @@ inline void bsdf_eval_pdf(const pbrt_material &m, V3 wi, V3 wo, V3 *f, float *pd
     }
 }
 
-inline BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, float s1, float s2x,
-                           float s2y) {
+// shf: the interaction's shading frame (si.to_local at CustomBSDF.py:165; read by ULTRA only)
+inline BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, const Frame &shf, float s1,
+                           float s2x, float s2y) {
     BSample b;
     b.valid = false;
     b.delta = false;
@@ -598,7 +609,7 @@ inline BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_
         }
         case PBRT_MAT_ULTRA: {
             float amp;
-            ultra_sample(m, quirks, wi, n_geo, n_sh, s1, s2x, s2y, &b.wo, &b.pdf, &amp, &b.lobe);
+            ultra_sample(m, quirks, wi, n_geo, n_sh, shf, s1, s2x, s2y, &b.wo, &b.pdf, &amp, &b.lobe);
             b.weight = {amp, amp, amp};
             b.delta = true;  // components are declared Delta* (CustomBSDF.py:22-26)
             b.valid = true;
@@ -700,10 +711,10 @@ UltraOut ultra_core(const pbrt_material &m, uint32_t quirks, V3 wi_in, V3 n_geo,
     return o;
 }
 
-void ultra_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, float s1, float s2x, float s2y,
-                  V3 *wo, float *pdf, float *amp, uint32_t *lobe) {
+void ultra_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, const Frame &shf, float s1, float s2x,
+                  float s2y, V3 *wo, float *pdf, float *amp, uint32_t *lobe) {
     UltraOut o = ultra_core(m, quirks, wi, n_geo, n_sh, s1, s2x, s2y);
-    *wo = to_local(make_frame(n_sh), o.chosen);  // :165 bs.wo = si.to_local(chosen_dir)
+    *wo = to_local(shf, o.chosen);  // :165 bs.wo = si.to_local(chosen_dir)
     *pdf = o.pdf;
     *amp = o.amp;
     *lobe = o.reflect ? 0u : 1u;
@@ -865,7 +876,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
         }
         // ---- BSDF sampling
         F4 ub = rng4(ka, kb, 2 + 2 * depth, seed);
-        BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, ub.x, ub.y, ub.z);
+        BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
         if (!bs.valid) break;
         thr = thr * bs.weight;
         eta *= bs.eta;
@@ -1127,8 +1138,9 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     float total_time = t0 + tof_hit + dist_recv * inv_c;                       // :329
                     float phase = two_pi_f * total_time;                                       // :330
                     const pbrt_material &M = sc.mats[si.prim->material];
-                    Frame fr = make_frame(si.n);
-                    V3 wi = to_local(fr, -d);                                                  // si.wi
+                    // si.sh_frame as Mitsuba builds it: from the shape's dp_du (initialize_sh_frame), not coordinate_system(n)
+                    const Frame fr = make_sh_frame(si.n, si_dp_du(si));
+                    V3 wi = to_local(fr, -d);                                                  // si.wi (CustomBSDF.py:90)
                     float a_resp, bpdf;
                     V3 new_dir;
                     if (M.type == PBRT_MAT_ULTRA) {
@@ -1138,7 +1150,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                         // :165 + :358: to_world(to_local(chosen))
                         new_dir = to_world(fr, to_local(fr, uo.chosen));
                     } else {
-                        BSample bs = bsdf_sample(M, p->quirks, wi, si.n, si.n, u.y, u.z, u.w);
+                        BSample bs = bsdf_sample(M, p->quirks, wi, si.n, si.n, fr, u.y, u.z, u.w);
                         if (!bs.valid) break;
                         a_resp = bs.weight.x;
                         bpdf = bs.pdf;
@@ -1198,12 +1210,13 @@ int oracle_ray_test(oracle_scene *s, uint32_t n, const float *o, const float *d,
 }
 
 int oracle_bsdf_sample(const pbrt_material *m, uint32_t quirks, uint32_t n, const float *wi, const float *n_geo,
-                       const float *n_sh, const float *s1, const float *s2, float *wo, float *pdf, float *weight,
-                       uint32_t *sampled) {
+                       const float *n_sh, const float *sh_s, const float *s1, const float *s2, float *wo, float *pdf,
+                       float *weight, uint32_t *sampled) {
     for (uint32_t i = 0; i < n; ++i) {
         V3 ng = n_geo ? v3(n_geo[i], n_geo[n + i], n_geo[2 * n + i]) : v3(0, 0, 1);
         V3 ns = n_sh ? v3(n_sh[i], n_sh[n + i], n_sh[2 * n + i]) : v3(0, 0, 1);
-        BSample b = bsdf_sample(*m, quirks, v3(wi[i], wi[n + i], wi[2 * n + i]), ng, ns, s1[i], s2[i], s2[n + i]);
+        const Frame shf = sh_s ? make_sh_frame(ns, v3(sh_s[i], sh_s[n + i], sh_s[2 * n + i])) : make_frame(ns);
+        BSample b = bsdf_sample(*m, quirks, v3(wi[i], wi[n + i], wi[2 * n + i]), ng, ns, shf, s1[i], s2[i], s2[n + i]);
         wo[i] = b.wo.x;
         wo[n + i] = b.wo.y;
         wo[2 * n + i] = b.wo.z;

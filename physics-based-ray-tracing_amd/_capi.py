@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbrt_hip.so")  # override: A/B builds
 
-PBRT_ABI_VERSION = 1
+PBRT_ABI_VERSION = 2
 
 # primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
@@ -141,7 +141,7 @@ SIGNATURES = {
     "pbrt_us_acquire_dev": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _F]),
     "pbrt_ray_intersect": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F, _F, _F, _F]),
     "pbrt_ray_test": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F]),
-    "pbrt_bsdf_sample": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F]),
+    "pbrt_bsdf_sample": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F]),
     "pbrt_bsdf_eval_pdf": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, _F, _F, _F, _F]),
     "pbrt_emitter_sample_direction": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F]),
     "pbrt_sensor_sample_ray": (C.c_int, [_P, C.POINTER(Camera), C.c_uint32, _F, _F, _F, _F]),

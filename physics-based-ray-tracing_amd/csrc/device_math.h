@@ -157,6 +157,18 @@ DEV Frame make_frame(V3 n) {
     f.n = n;
     return f;
 }
+// Mitsuba SurfaceInteraction::initialize_sh_frame(): s = normalize(dp_du - n (n . dp_du)), t = n x s -- the frame
+// si.wi, si.to_local and si.to_world use (CustomBSDF.py:90,165; CustomIntegrator.py:358).  Zero dp_du: coordinate_system(n).
+DEV Frame make_sh_frame(V3 n, V3 dp_du) {
+    V3 s = madd(n, -dot(n, dp_du), dp_du);
+    float l2 = dot(s, s);
+    if (!(l2 > 0.0f)) return make_frame(n);
+    Frame f;
+    f.s = s * (1.0f / sqrtf(l2));
+    f.t = cross(n, f.s);
+    f.n = n;
+    return f;
+}
 DEV V3 to_local(const Frame &f, V3 v) { return {dot(v, f.s), dot(v, f.t), dot(v, f.n)}; }
 DEV V3 to_world(const Frame &f, V3 v) {
     return {fma_(f.s.x, v.x, fma_(f.t.x, v.y, f.n.x * v.z)), fma_(f.s.y, v.x, fma_(f.t.y, v.y, f.n.y * v.z)),

@@ -540,6 +540,19 @@ DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
     return si;
 }
 
+// dp_du of the interaction, the input of Mitsuba's shading frame (make_sh_frame):
+//   triangle / parallelogram: the first edge e1 (Mesh without texture coordinates: dp_du = p1 - p0; `rectangle`:
+//     to_world * (2, 0, 0), which is e1 of its parallelogram record)
+//   sphere: 2 pi (-y, x, 0) of the hit point about the centre (Sphere::compute_surface_interaction; the record holds
+//     centre + radius only, so the sphere's object axes are taken parallel to the world's)
+//   cone ([DEFINE] shape, no Mitsuba definition): none -> coordinate_system(n)
+template <bool CONES = true>
+DEV V3 si_dp_du(const pbrt_prim &P, const SI &si) {
+    if (P.type == PBRT_PRIM_SPHERE) return {-(si.p.y - P.g[1]), si.p.x - P.g[0], 0.0f};
+    if (CONES && P.type == PBRT_PRIM_CONE) return {0.0f, 0.0f, 0.0f};
+    return g3(P, 3);
+}
+
 // ---- UltraBSDF.sample: CustomBSDF.py:87-175 (+ _ggx_sample :30-61, ggx_pdf :64-83) --------------
 struct UltraOut {
     V3 chosen;
@@ -636,8 +649,9 @@ DEV void bsdf_eval_pdf(const pbrt_material &m, V3 wi, V3 wo, V3 *f, float *pdf) 
     }
 }
 
-DEV BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, float s1, float s2x,
-                        float s2y) {
+// shf: the interaction's shading frame (si.to_local at CustomBSDF.py:165; read by ULTRA only)
+DEV BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo, V3 n_sh, const Frame &shf, float s1,
+                        float s2x, float s2y) {
     BSample b;
     b.valid = false;
     b.delta = false;
@@ -694,7 +708,7 @@ DEV BSample bsdf_sample(const pbrt_material &m, uint32_t quirks, V3 wi, V3 n_geo
         }
     } else if (type == PBRT_MAT_ULTRA) {
         UltraOut o = ultra_core(m, quirks, wi, n_geo, n_sh, s1, s2x, s2y);
-        b.wo = to_local(make_frame(n_sh), o.chosen);  // CustomBSDF.py:165
+        b.wo = to_local(shf, o.chosen);  // CustomBSDF.py:165
         b.pdf = o.pdf;
         b.weight = {o.amp, o.amp, o.amp};
         b.lobe = o.reflect ? 0u : 1u;

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
                 }
                 // ---- BSDF sampling, continuation ray, Russian roulette
                 F4 ub = rng4(ka, kb, 2 + 2 * depth, a.seed);
-                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, ub.x, ub.y, ub.z);
+                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
                 if (bs.valid) {
                     thr = thr * bs.weight;
                     eta *= bs.eta;

@@ -219,8 +219,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             }
             atten *= expf(a.katt * distance / 8.686f);                                 // :328
             const pbrt_material M = tb.mats[P.material];
-            Frame fr = make_frame(si.n);
-            V3 wi = to_local(fr, -d);
+            // si.sh_frame as Mitsuba builds it (from dp_du, not coordinate_system(n)): si.wi, si.to_local, si.to_world
+            const Frame fr = make_sh_frame(si.n, si_dp_du<ACCEL != ACCEL_K_BRUTE>(P, si));
+            V3 wi = to_local(fr, -d);                                                  // si.wi (CustomBSDF.py:90)
             float a_resp, bpdf;
             V3 new_dir;
             bool ok = true;
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                 bpdf = uo.pdf;
                 new_dir = to_world(fr, to_local(fr, uo.chosen));                       // CustomBSDF.py:165 + :358
             } else {
-                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, u.w);
+                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.n, fr, u.y, u.z, u.w);
                 ok = bs.valid;
                 a_resp = bs.weight.x;
                 bpdf = bs.pdf;
@@ -430,13 +431,15 @@ __global__ __launch_bounds__(256) void k_ray_test(DevScene sc, uint32_t n, const
 }
 
 __global__ __launch_bounds__(256) void k_bsdf_sample(pbrt_material m, uint32_t quirks, uint32_t n, const float *wi,
-                                                     const float *ng, const float *ns, const float *s1, const float *s2,
-                                                     float *wo, float *pdf, float *weight, uint32_t *sampled) {
+                                                     const float *ng, const float *ns, const float *shs, const float *s1,
+                                                     const float *s2, float *wo, float *pdf, float *weight, uint32_t *sampled) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     V3 g = ng ? v3(ng[i], ng[n + i], ng[2 * n + i]) : v3(0, 0, 1);
     V3 s = ns ? v3(ns[i], ns[n + i], ns[2 * n + i]) : v3(0, 0, 1);
-    BSample b = bsdf_sample(m, quirks, v3(wi[i], wi[n + i], wi[2 * n + i]), g, s, s1[i], s2[i], s2[n + i]);
+    // si.sh_frame: its tangent when the caller has one (dp_du / sh_frame.s), else coordinate_system(n_sh)
+    const Frame shf = shs ? make_sh_frame(s, v3(shs[i], shs[n + i], shs[2 * n + i])) : make_frame(s);
+    BSample b = bsdf_sample(m, quirks, v3(wi[i], wi[n + i], wi[2 * n + i]), g, s, shf, s1[i], s2[i], s2[n + i]);
     wo[i] = b.wo.x;
     wo[n + i] = b.wo.y;
     wo[2 * n + i] = b.wo.z;

@@ -529,10 +529,14 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             a.seg_in = sin;
             a.seg_out = sout;
             if (repack && depth >= 2) {
+                // Only the regions THIS pass launched take part: a short last pass (spp not a multiple of the pass size)
+                // launches nseg_pass < nseg workgroups, so paths dealt to regions >= nseg_pass would never be traced, and
+                // the counters of those regions are left over from the previous pass.
                 const uint32_t owners = rad_owners_per_region(s->accel_kernel), wreg = REGION / owners;
-                hipLaunchKernelGGL(k_scan_owners, dim3(1), dim3(1024), 0, st, sin, n_own, wreg, owners, (uint32_t)c->n_cu, offs, segC,
-                                   quota);
-                hipLaunchKernelGGL(k_repack_copy, dim3(n_own), dim3(256), 0, st, in, stC, sin, offs, quota, n_own, wreg);
+                const uint32_t n_own_pass = nseg_pass * owners;
+                hipLaunchKernelGGL(k_scan_owners, dim3(1), dim3(1024), 0, st, sin, n_own_pass, wreg, owners, (uint32_t)c->n_cu, offs,
+                                   segC, quota);
+                hipLaunchKernelGGL(k_repack_copy, dim3(n_own_pass), dim3(256), 0, st, in, stC, sin, offs, quota, n_own_pass, wreg);
                 a.in = stC;
                 a.seg_in = segC;
             }
@@ -1073,16 +1077,17 @@ int pbrt_ray_test(pbrt_scene *s, uint32_t n, const float *o, const float *d, con
 }
 
 int pbrt_bsdf_sample(pbrt_ctx *ctx, const pbrt_material *m, uint32_t quirks, uint32_t n, const float *wi,
-                     const float *n_geo, const float *n_sh, const float *s1, const float *s2, float *wo, float *pdf,
-                     float *weight, uint32_t *sampled) {
+                     const float *n_geo, const float *n_sh, const float *sh_s, const float *s1, const float *s2, float *wo,
+                     float *pdf, float *weight, uint32_t *sampled) {
     if (!ctx) return PBRT_E_INVALID;
     NEED(ctx, m && wi && s1 && s2 && wo && pdf && weight && sampled);
-    LEAF_BEGIN(ctx, (size_t)n * 4 * 22);
+    LEAF_BEGIN(ctx, (size_t)n * 4 * 25);
     float *dwi = S.in(wi, 3 * (size_t)n), *dng = S.in(n_geo, 3 * (size_t)n), *dns = S.in(n_sh, 3 * (size_t)n);
+    float *dss = S.in(sh_s, 3 * (size_t)n);
     float *d1 = S.in(s1, n), *d2 = S.in(s2, 2 * (size_t)n);
     float *rwo = S.out<float>(3 * (size_t)n), *rpdf = S.out<float>(n), *rw = S.out<float>(3 * (size_t)n);
     uint32_t *rs = S.out<uint32_t>(n);
-    hipLaunchKernelGGL(k_bsdf_sample, grid, block, 0, st, *m, quirks, n, dwi, dng, dns, d1, d2, rwo, rpdf, rw, rs);
+    hipLaunchKernelGGL(k_bsdf_sample, grid, block, 0, st, *m, quirks, n, dwi, dng, dns, dss, d1, d2, rwo, rpdf, rw, rs);
     S.back(wo, rwo, 3 * (size_t)n);
     S.back(pdf, rpdf, n);
     S.back(weight, rw, 3 * (size_t)n);

@@ -103,10 +103,12 @@ def distributed_render(scene, spp, seed=0, band_rows=64, render_band=None, devic
     return gather_film(tile, layout, W, H, rank, world, group)
 
 
-def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None):
+def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None, apply_pulse=None):
     """Ultrasound: every rank traces its path range into its own (already normalised) channel buffer;
     one reduce(sum) to rank 0.  acquire(offset, count, norm, out_tensor) fills the tensor; the default
-    calls the HIP library on the tensor's device memory.  -> [n_angles, n_elements, T] tensor on rank 0."""
+    calls the HIP library on the tensor's device memory.  With pulse_model 'gaussian' rank 0 convolves the reduced
+    buffer with the pulse (apply_pulse: None = follow the integrator, False = never, True / callable = do it).
+    -> [n_angles, n_elements, T] tensor on rank 0."""
     import torch
 
     dist = _dist()
@@ -125,10 +127,24 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
             if dev.type != "cuda":
                 raise RuntimeError("the HIP acquisition path needs a device tensor")
             ui._acquire(scene, ui.quirks, paths_per_ray=cnt, path_offset=off, norm_paths=paths_per_ray, seed=seed,
-                        out_dev=buf.data_ptr())
+                        out_dev=buf.data_ptr(), pulse=False)
     if world > 1:
         dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
-    return buf if rank == 0 else None
+    if rank != 0:
+        return None
+    if apply_pulse is None:
+        apply_pulse = getattr(ui, "pulse_model", "impulse") == "gaussian"
+    if apply_pulse:
+        # pulse_model 'gaussian': the shards hold bare echo amplitudes; the pulse is linear, so ONE convolution of the
+        # reduced buffer equals the single-GPU result (UltraIntegrator._acquire applies it to its host buffer).
+        # apply_pulse may be a callable (traces, fs, frequency, sigma) -> traces (CPU tests pass the restatement).
+        if callable(apply_pulse):
+            _pulse = apply_pulse
+        else:
+            from .beamform import apply_pulse as _pulse
+        host = _pulse(buf.detach().cpu().numpy(), ui.fs, ui.frequency, ui.pulse_sigma)
+        buf = torch.from_numpy(np.ascontiguousarray(host, dtype=np.float32)).to(buf.device)
+    return buf
 
 
 # ---- radiance mode, sharded by SAMPLES -------------------------------------------------------------------------------

@@ -76,12 +76,15 @@ class SurfaceInteraction3f:
         def __init__(self, n):
             self.n = n
 
-    def __init__(self, wi, n=None, sh_n=None):
+    def __init__(self, wi, n=None, sh_n=None, sh_s=None):
+        """sh_s: tangent of the shading frame (sh_frame.s, or the shape's dp_du: Mitsuba orthonormalises it against
+        sh_frame.n); None = coordinate_system(sh_frame.n)"""
         self.wi = np.atleast_2d(np.asarray(wi, dtype=np.float32))
         cnt = len(self.wi)
         z = np.tile(np.array([[0, 0, 1]], np.float32), (cnt, 1))
         self.n = np.atleast_2d(np.asarray(n, dtype=np.float32)) if n is not None else z
         self.sh_frame = self._Frame(np.atleast_2d(np.asarray(sh_n, dtype=np.float32)) if sh_n is not None else self.n)
+        self.sh_frame.s = np.atleast_2d(np.asarray(sh_s, dtype=np.float32)) if sh_s is not None else None
 
 
 class BSDF(BSDFBase):
@@ -107,9 +110,11 @@ class BSDF(BSDFBase):
         lobe = np.empty(n, np.uint32)
         cx = _capi.default_context()
         m = self._material()
+        shs = _soa3(si.sh_frame.s, n) if getattr(si.sh_frame, "s", None) is not None else None
         cx.check(cx.lib.pbrt_bsdf_sample(cx.handle, C.byref(m), int(self._quirks), n, _capi.addr(wi), _capi.addr(ng),
-                                         _capi.addr(ns), _capi.addr(s1), _capi.addr(s2), _capi.addr(wo), _capi.addr(pdf),
-                                         _capi.addr(weight), _capi.addr(lobe)), "pbrt_bsdf_sample")
+                                         _capi.addr(ns), _capi.addr(shs) if shs is not None else None, _capi.addr(s1),
+                                         _capi.addr(s2), _capi.addr(wo), _capi.addr(pdf), _capi.addr(weight),
+                                         _capi.addr(lobe)), "pbrt_bsdf_sample")
         bs = BSDFSample3f(wo.T.copy(), pdf, np.ones(n, np.float32), self._sampled_type(lobe), lobe)
         return bs, self._weight_out(weight)
 
@@ -735,13 +740,21 @@ class UltraIntegrator(SamplingIntegrator):
         p.quirks = int(self.quirks if quirks is None else quirks)
         return p
 
-    def _acquire(self, scene, quirks, paths_per_ray=None, path_offset=0, norm_paths=None, seed=None, out_dev=None):
+    def _acquire(self, scene, quirks, paths_per_ray=None, path_offset=0, norm_paths=None, seed=None, out_dev=None, pulse=None):
+        """pulse: apply the Gaussian-windowed carrier when the echoes were deposited without one (pulse_model
+        'gaussian' = PBRT_USQ_NO_CARRIER).  Default: yes for a host buffer.  A device buffer (out_dev) is one shard of a
+        sum that is still to be reduced, so the caller convolves the REDUCED buffer once (parallel.distributed_acquire
+        does) and says pulse=False here; leaving it unsaid is an error rather than a silently carrier-less result."""
         ppr = int(paths_per_ray if paths_per_ray is not None else self.paths_per_ray)
         norm = int(norm_paths if norm_paths is not None else ppr)
         p = self.us_params(scene, quirks)
         dev = scene.device()
         tx = np.empty(self.n_angles * self.n_elements, np.float32)
         sd = int(self.seed if seed is None else seed) & 0xFFFFFFFF
+        no_carrier = bool(int(p.quirks) & _capi.USQ_NO_CARRIER)
+        if out_dev is not None and no_carrier and pulse is not False:
+            raise ValueError("pulse_model 'gaussian' with a device output buffer: the pulse is applied to the reduced buffer "
+                             "(parallel.distributed_acquire); pass pulse=False to get this shard's bare echo amplitudes")
         if out_dev is not None:
             dev.ctx.check(dev.ctx.lib.pbrt_us_acquire_dev(dev.handle, C.byref(p), sd, ppr, int(path_offset), norm,
                                                            C.c_void_p(int(out_dev)), _capi.addr(tx)), "pbrt_us_acquire_dev")
@@ -752,7 +765,7 @@ class UltraIntegrator(SamplingIntegrator):
                                                        _capi.addr(buf), _capi.addr(tx)), "pbrt_us_acquire")
         self.transmission_delays_buf = tx
         self.ray_count = int(dev.ctx.stats()["segments"])
-        if buf is not None and (int(p.quirks) & _capi.USQ_NO_CARRIER):
+        if buf is not None and no_carrier and pulse is not False:
             # f-3 pulse model: the echoes were deposited as plain amplitudes; give every trace the Gaussian-windowed carrier
             from .beamform import apply_pulse
             buf = apply_pulse(buf, self.fs, self.frequency, self.pulse_sigma)

@@ -1,0 +1,193 @@
+"""Generates the fixtures K9 (ultrasound) and K10 (radiance) with tests/golden/ref_transcription.py, the float64
+restatement written from the reference's Python -- NOT from oracle/oracle.cpp (see that module's header).
+
+Run in the build container (reads the reference's cbox OBJ quads as data):   python tests/golden/make_pinned.py
+Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k10_cbox_paths.npz
+
+K9  scenes:  'plate'       the scene USMain.py:26-90 builds (tilted plate 5 cm ahead, back wall at 1 m; integrator block :28-42)
+             'sphere_box'  MitsubaScenes/Sphere_Box.xml:2-101 with the author-intent transforms
+    every (angle, element, path k) ray is traced by us_trace_single_ray with the draws rng4(ray, k, bounce, seed);
+    the fixture holds every echo bin (index, summed pressure, summed envelope, the smallest decision margin among
+    its contributors) and a set of single-bounce BSDF records (wi, n, sh_frame.s, s1, s2 -> wo, pdf, amplitude).
+K10 the Cornell box of scenes/cbox.xml (camera :11-21, materials :36-54, spheres :115-129, quads from
+    scenes/meshes/cbox_*.obj, luminaire translated by -0.01 :60-62, radiance (1,1,1) :75 / DESIGN D1), 24 x 24 pixels,
+    samples 0 and 1 of every pixel, max_depth 6: per-sample radiance of path_radiance + decision margin.
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_transcription as rt  # noqa: E402
+
+REF = "/root/reference"
+
+
+def Rx(a):
+    c, s = math.cos(math.radians(a)), math.sin(math.radians(a))
+    M = np.eye(4)
+    M[1, 1], M[1, 2], M[2, 1], M[2, 2] = c, -s, s, c
+    return M
+
+
+def Ry(a):
+    c, s = math.cos(math.radians(a)), math.sin(math.radians(a))
+    M = np.eye(4)
+    M[0, 0], M[0, 2], M[2, 0], M[2, 2] = c, s, -s, c
+    return M
+
+
+def Tr(x, y, z):
+    M = np.eye(4)
+    M[:3, 3] = [x, y, z]
+    return M
+
+
+def Sc(x, y, z):
+    return np.diag([x, y, z, 1.0])
+
+
+US_SCENES = {
+    # USMain.py:26-90: integrator :28-42, sensor look_at :53-57 (identity), flat_plate :67-75, wall_back :79-87
+    "plate": dict(
+        params=dict(max_depth=10, fs=50e6, frequency=5e6, sound_speed=1540.0, attenuation=0.2, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        look_at=([0, 0, 0], [0, 0, 0.03], [0, 1, 0]),
+        shapes=[dict(type="rectangle", to_world=Tr(0, 0, 0.05) @ Ry(45) @ Sc(0.17, 0.17, 0.14), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0, 1) @ Ry(180) @ Sc(0.05, 0.05, 1), impedance=7.8, roughness=0.7)],
+        seed=11, ppr=2),
+    # MitsubaScenes/Sphere_Box.xml: integrator :2-15, sensor :16-34 (identity), sphere :36-45, walls :47-101 (T @ R @ S)
+    "sphere_box": dict(
+        params=dict(max_depth=10, fs=50e6, frequency=3e6, sound_speed=1480.0, attenuation=0.1, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        look_at=([0, 0, 0], [0, 0, 0.05], [0, 1, 0]),
+        shapes=[dict(type="sphere", center=[0, 0, 0.08], radius=0.06, impedance=7.8, roughness=0.9),
+                dict(type="rectangle", to_world=Tr(0, 0, 0.37) @ Ry(180) @ Sc(0.15, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(-0.15, 0, 0.12) @ Ry(90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0.15, 0, 0.12) @ Ry(-90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
+        seed=7, ppr=3),
+}
+
+
+def build_shapes(desc):
+    out = []
+    for d in desc:
+        bs = dict(impedance=d["impedance"], roughness=d["roughness"])
+        if d["type"] == "sphere":
+            out.append(rt.Sphere(d["center"], d["radius"], bsdf=bs))
+        else:
+            out.append(rt.Parallelogram.rectangle(d["to_world"], bsdf=bs))
+    return out
+
+
+def make_k9(name, S):
+    shapes = build_shapes(S["shapes"])
+    P, seed, ppr = S["params"], S["seed"], S["ppr"]
+    T = rt.look_at(*S["look_at"])
+    NA, NE = len(P["angles_deg"]), P["n_elements"]
+    bins, recs = {}, []
+    n_bounces = 0
+    for a in range(NA):
+        for e in range(NE):
+            ray = a * NE + e
+            for k in range(ppr):
+                out = rt.us_trace_single_ray(shapes, T, P, a, e, lambda dep: rt.rng4(ray, k, dep, seed))
+                n_bounces += len(out)
+                for r in out:
+                    recs.append(r)
+                    if r["deposited"]:
+                        b = bins.setdefault((a, r["recv"], r["t_idx"]), dict(p=0.0, env=0.0, env_abs=0.0, margin=math.inf, n=0))
+                        b["p"] += r["pressure"]
+                        b["env"] += r["envelope"]
+                        b["env_abs"] += abs(r["envelope"])
+                        b["margin"] = min(b["margin"], r["margin"])
+                        b["n"] += 1
+                # a decision that may flip in f32 changes everything after it: later bounces inherit the margin
+                m = math.inf
+                for r in out:
+                    m = min(m, r["margin"])
+                    if r["deposited"]:
+                        b = bins[(a, r["recv"], r["t_idx"])]
+                        b["margin"] = min(b["margin"], m)
+    keys = sorted(bins)
+    # single-bounce BSDF records: well-conditioned ones, spread over lobes / TIR / depths
+    good = [r for r in recs if r["margin"] >= 1e-2]
+    pick = []
+    for cond in (lambda r: r["tir"], lambda r: r["reflect"] and not r["tir"], lambda r: not r["reflect"], lambda r: r["depth"] >= 1):
+        sel = [r for r in good if cond(r)]
+        pick += sel[:: max(1, len(sel) // 16)][:16]
+    meta = dict(scene=name, params=P, look_at=S["look_at"], seed=seed, paths_per_ray=ppr, n_bounces=n_bounces,
+                shapes=[{k: (np.asarray(v).tolist() if k in ("to_world", "center") else v) for k, v in d.items()} for d in S["shapes"]],
+                depth_histogram={str(d): sum(1 for r in recs if r["depth"] == d) for d in sorted({r["depth"] for r in recs})})
+    np.savez_compressed(
+        os.path.join(HERE, f"k9_us_{name}.npz"), meta=json.dumps(meta),
+        bin_index=np.array(keys, np.int32).reshape(-1, 3), bin_pressure=np.array([bins[k]["p"] for k in keys]),
+        bin_envelope=np.array([bins[k]["env"] for k in keys]), bin_envelope_abs=np.array([bins[k]["env_abs"] for k in keys]),
+        bin_margin=np.array([bins[k]["margin"] for k in keys]), bin_count=np.array([bins[k]["n"] for k in keys], np.int32),
+        rec_wi=np.array([r["wi"] for r in pick]), rec_n=np.array([r["n"] for r in pick]), rec_sh_s=np.array([r["sh_s"] for r in pick]),
+        rec_s1=np.array([r["s1"] for r in pick]), rec_s2=np.array([r["s2"] for r in pick]), rec_wo=np.array([r["wo"] for r in pick]),
+        rec_pdf=np.array([r["pdf"] for r in pick]), rec_a_resp=np.array([r["a_resp"] for r in pick]),
+        rec_reflect=np.array([r["reflect"] for r in pick]), rec_tir=np.array([r["tir"] for r in pick]),
+        rec_new_dir=np.array([r["new_dir"] for r in pick]), rec_shape=np.array([r["shape"] for r in pick], np.int32),
+        rec_depth=np.array([r["depth"] for r in pick], np.int32))
+    safe = sum(1 for k in keys if bins[k]["margin"] >= 1e-2)
+    print(f"k9_us_{name}.npz: {n_bounces} bounces {meta['depth_histogram']}, {len(keys)} bins ({safe} with margin >= 1e-2), {len(pick)} BSDF records")
+
+
+# ---- K10 --------------------------------------------------------------------------------------------------------------
+def obj_quad(path):
+    v = [list(map(float, ln.split()[1:4])) for ln in open(path) if ln.startswith("v ")]
+    f = [ln.split()[1:] for ln in open(path) if ln.startswith("f ")]
+    assert len(f) == 1 and len(f[0]) == 4
+    return [np.array(v[int(t.split("/")[0]) - 1]) for t in f[0]]
+
+
+def cbox_shapes():
+    white = dict(type="diffuse", reflectance=[0.885809, 0.698859, 0.666422])   # scenes/cbox.xml:36-42
+    green = dict(type="diffuse", reflectance=[0.105421, 0.37798, 0.076425])    # :44-46
+    red = dict(type="diffuse", reflectance=[0.570068, 0.0430135, 0.0443706])   # :48-50
+    mesh = os.path.join(REF, "scenes", "meshes")
+
+    def quad(name, bsdf, emitter=None, dy=0.0):
+        a, b, c, d = (p + np.array([0.0, dy, 0.0]) for p in obj_quad(os.path.join(mesh, name)))
+        assert np.allclose(a + c, b + d)
+        return rt.Parallelogram(a, b - a, d - a, bsdf=bsdf, emitter=emitter)
+
+    light = quad("cbox_luminaire.obj", white, dict(radiance=[1.0, 1.0, 1.0]), dy=-0.01)   # :58-86
+    shapes = [light, quad("cbox_floor.obj", white), quad("cbox_ceiling.obj", white), quad("cbox_back.obj", white),
+              quad("cbox_greenwall.obj", green), quad("cbox_redwall.obj", red),
+              rt.Sphere([-0.3, -0.5, 0.2], 0.5, bsdf=dict(type="conductor")),                    # :115-121
+              rt.Sphere([0.5, -0.75, -0.2], 0.25, bsdf=dict(type="dielectric", eta=1.5046 / 1.000277))]   # :123-129, bk7 / air
+    return shapes, [light]
+
+
+def make_k10():
+    res, seed, max_depth, rr_depth, n_s = 24, 5, 6, 5, 2
+    shapes, lights = cbox_shapes()
+    cam = dict(x_fov=39.3077, width=res, height=res, near=0.001, far=100.0, to_world=rt.look_at([0, 0, 4], [0, 0, 0], [0, 1, 0]))
+    L = np.zeros((n_s, res, res, 3))
+    M = np.zeros((n_s, res, res))
+    for s in range(n_s):
+        for y in range(res):
+            for x in range(res):
+                pix = y * res + x
+                uj = rt.rng4(pix, s, 0, seed)                       # block 0: pixel jitter
+                o, d, tmax = rt.perspective_ray(cam, (x + uj[0]) / res, (y + uj[1]) / res)
+                L[s, y, x], M[s, y, x] = rt.path_radiance(shapes, lights, o, d, tmax, (pix, s), seed, max_depth, rr_depth)
+    meta = dict(res=res, seed=seed, max_depth=max_depth, rr_depth=rr_depth, samples=n_s, x_fov=39.3077, near=0.001, far=100.0,
+                quads=[dict(p0=q.p0.tolist(), e1=q.e1.tolist(), e2=q.e2.tolist()) for q in shapes[:6]])
+    np.savez_compressed(os.path.join(HERE, "k10_cbox_paths.npz"), meta=json.dumps(meta), radiance=L, margin=M)
+    print(f"k10_cbox_paths.npz: {n_s} x {res} x {res} paths, mean radiance {L.mean():.5f}, "
+          f"{(M >= 1e-3).mean() * 100:.1f} % with margin >= 1e-3")
+
+
+if __name__ == "__main__":
+    for name, S in US_SCENES.items():
+        make_k9(name, S)
+    make_k10()

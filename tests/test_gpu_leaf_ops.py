@@ -138,6 +138,13 @@ def test_bsdf_sample_and_eval(mi, ob, capi, kind):
         assert np.array_equal(f, fr) and np.array_equal(p, pr)
     valid = lobe != 0xFFFFFFFF
     assert valid.mean() > 0.4
+    if kind.startswith("ultra"):
+        # with the tangent of the interaction's shading frame (Mitsuba builds sh_frame from dp_du): only bs.wo moves
+        sh_s = rng.normal(size=(n, 3)).astype(np.float32)
+        bs2, w2 = b.sample(mi.BSDFContext(), mi.SurfaceInteraction3f(wi, ng, ng, sh_s=sh_s), s1, s2)
+        wo2, pdf2, wref2, lobe2 = ob.bsdf_sample(m, quirks, wi, ng, ng, s1, s2, sh_s=sh_s)
+        assert np.array_equal(bs2.wo, wo2) and np.array_equal(bs2.pdf, pdf) and np.array_equal(w2, w)
+        assert not np.array_equal(wo2, wo) and np.allclose(np.linalg.norm(wo2, axis=1), np.linalg.norm(wo, axis=1), rtol=1e-4)
 
 
 def test_reference_style_scalar_sample2(mi, ob, capi):

@@ -244,3 +244,20 @@ def test_bvh_scene_at_scale_queue_and_repack(mi, ob, capi):
     assert np.array_equal(img[150:174], ref) and img.mean() > 0
     st = mi.default_context().stats()
     assert st["samples"] == 320 * 320 * 12 and st["live"][0] == st["samples"] and st["live"][2] < st["live"][1] < st["live"][0]
+
+
+def test_bvh_repack_with_a_short_last_pass(mi, ob, capi):
+    """spp that does not split into equal passes: 13 samples at 300 000 paths per pass are 6 passes of 2 and one of 1,
+    so the last pass launches half the regions the workspace was sized for.  The re-dealing of the live paths before
+    bounces >= 2 must stay inside the regions that pass launched (and must not read the counters the previous pass
+    left behind in the others); an odd max_depth leaves survivors in both counter arrays."""
+    sc = mi.load_file(scene_path("testring.xml"), res=320, spp=13, max_depth=7)
+    integ = sc.integrator()
+    img = integ.render(sc, seed=3, spp=13)
+    short = integ.render(sc, seed=3, spp=13, pass_paths=300_000)
+    assert np.array_equal(short, img)
+    assert np.array_equal(integ.render(sc, seed=3, spp=13, pass_paths=300_000, flags=capi.FILM_NO_REPACK), img)
+    assert mi.default_context().stats()["passes"] == 7
+    band = (0, 160, 320, 16)
+    ref, _ = oracle_render(ob, sc, 3, 13, crop=band)
+    assert np.array_equal(short[160:176], ref)

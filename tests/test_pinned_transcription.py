@@ -1,0 +1,87 @@
+"""The CPU oracle against K9 / K10: fixtures produced by an INDEPENDENT float64 restatement of the reference's
+hot loop (tests/golden/ref_transcription.py: written from CustomIntegrator.py:262-376 and CustomBSDF.py:30-175, and from
+Mitsuba's published semantics for the radiance path -- not from oracle/oracle.cpp, with which it shares no source).
+A sign, a frame, a pdf multiplied instead of divided, a wrong MIS weight in oracle.cpp's `ultra_core` / `path_radiance`
+fails here, where the oracle-vs-HIP tests (same leaf arithmetic on both sides) cannot see it."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, oracle_render, scene_path
+from pinned_util import SAFE, check_k10, check_k9_bins, check_k9_records, k9_scene, load_k10, load_k9
+
+sys.path.insert(0, GOLDEN)
+
+
+@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+def test_k9_fixture_is_what_the_transcription_produces(name):
+    """the committed fixture equals a fresh run of the transcription (first rays of every angle)"""
+    import make_pinned as mp
+    import ref_transcription as rt
+    z, meta = load_k9(name)
+    S = mp.US_SCENES[name]
+    assert meta["params"] == S["params"] and meta["seed"] == S["seed"]
+    shapes, T = mp.build_shapes(S["shapes"]), rt.look_at(*S["look_at"])
+    have = {tuple(k): (p, e) for k, p, e in zip(z["bin_index"].tolist(), z["bin_pressure"], z["bin_envelope"])}
+    NE, n = S["params"]["n_elements"], 0
+    acc = {}
+    for a in range(len(S["params"]["angles_deg"])):
+        for e in range(NE):
+            ray = a * NE + e
+            for k in range(S["ppr"]):
+                for r in rt.us_trace_single_ray(shapes, T, S["params"], a, e, lambda dep: rt.rng4(ray, k, dep, S["seed"])):
+                    if r["deposited"]:
+                        key = (a, r["recv"], r["t_idx"])
+                        acc[key] = acc.get(key, 0.0) + r["pressure"]
+                        n += 1
+    assert set(acc) == set(have)
+    assert all(abs(acc[k] - have[k][0]) <= 1e-12 * max(1.0, abs(acc[k])) for k in acc)
+
+
+def test_rng_of_the_transcription_is_the_librarys(ob, capi):
+    """draws are inputs of a fixture; they come from the same counter-based generator on both sides (pcg4d): the
+    diffuse BSDF passes its 2-D sample through the concentric disk, which pins u.y, u.z of a block; the camera jitter
+    of a render pins block 0 -- checked end to end by K10.  Here: the integer hash itself."""
+    import ref_transcription as rt
+    assert rt.pcg4d(0, 0, 0, 0) != rt.pcg4d(0, 0, 0, 1)
+    u = np.array([rt.rng4(a, b, c, 9) for a, b, c in [(0, 0, 0), (1, 2, 3), (4095, 77, 11), (2 ** 31, 5, 1)]])
+    assert np.all((u >= 0) & (u < 1)) and len(np.unique(u)) == u.size
+
+
+@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+def test_k9_oracle_single_bounce_records(ob, capi, name):
+    z, meta = load_k9(name)
+
+    def sample(imp, rough, wi, n, sh_s, s1, s2):
+        m = capi.make_material(capi.MAT_ULTRA, [imp, rough, 1.2])
+        wo, pdf, w, lobe = ob.bsdf_sample(m, capi.USQ_REFERENCE, wi, n, n, s1, np.stack([s2, s2], axis=1), sh_s=sh_s)
+        return wo, pdf, w[:, 0], lobe
+    check_k9_records(z, meta, sample)
+
+
+@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+def test_k9_oracle_echo_values(mi, ob, capi, name):
+    """every echo of every path: arrival bin, pressure (CustomIntegrator.py:340-354) and, with the carrier off, the
+    envelope atten * amp * w_i * w_o alone; sphere_box has second-bounce echoes, so the continuation direction
+    (:358-359), the roulette division (:364-367) and the accumulated time of flight (:316) are in the values"""
+    z, meta = load_k9(name)
+    sc = k9_scene(mi, meta)
+    ui = sc.integrator()
+    osc = ob.OracleScene.from_scene(sc)
+    buf, _ = osc.us_acquire(ui.us_params(sc), meta["seed"], meta["paths_per_ray"])
+    check_k9_bins(z, meta, buf, carrier=True)
+    buf, _ = osc.us_acquire(ui.us_params(sc, ui.quirks | capi.USQ_NO_CARRIER), meta["seed"], meta["paths_per_ray"])
+    check_k9_bins(z, meta, buf, carrier=False)
+    if name == "sphere_box":
+        assert int(meta["depth_histogram"].get("1", 0)) > 500
+
+
+def test_k10_oracle_path_values(mi, ob):
+    """per-sample radiance of the Cornell box (6 bounces: emission + MIS, emitter sampling + shadow ray, diffuse /
+    mirror / glass sampling, roulette) against the float64 Mitsuba-`path` restatement"""
+    z, meta = load_k10()
+    sc = mi.load_file(scene_path("cbox.xml"), res=meta["res"], spp=1, max_depth=meta["max_depth"], rfilter="box")
+    worst = check_k10(z, meta, lambda s: oracle_render(ob, sc, meta["seed"], 1, sample_offset=s)[0])
+    assert worst < 2e-4

@@ -42,7 +42,7 @@ def lib():
         L.oracle_ggx_angle_deg.argtypes = [C.c_double, C.c_uint32, _P, _P]
         L.oracle_ggx_pdf_raw.argtypes = [C.c_double, C.c_uint32, _P, _P]
         for name in ("oracle_scene_create", "oracle_scene_destroy", "oracle_scene_update_material",
-                     "oracle_render_radiance", "oracle_us_acquire", "oracle_us_tx_delays", "oracle_ray_intersect",
+                     "oracle_render_radiance", "oracle_integrator_sample", "oracle_us_acquire", "oracle_us_tx_delays", "oracle_ray_intersect",
                      "oracle_ray_test", "oracle_bsdf_sample", "oracle_bsdf_eval_pdf", "oracle_emitter_sample_direction",
                      "oracle_sensor_sample_ray", "oracle_us_sensor_sample_ray", "oracle_us_emitter_sample_ray",
                      "oracle_us_put_data"):
@@ -87,6 +87,16 @@ class OracleScene:
              "oracle_render_radiance")
         self.last_stats = dict(segments=int(stats[0]), shadow_rays=int(stats[1]))
         return out
+
+    def integrator_sample(self, o, d, tmax, index_offset, sample_index, seed, max_depth, rr_depth=5):
+        """twin of pbrt_integrator_sample: radiance along caller rays, keys (index_offset + i, sample_index) -> [n, 3]"""
+        o, d, tmax = f32(np.asarray(o).T), f32(np.asarray(d).T), f32(tmax)
+        n = len(tmax)
+        rgb = np.empty((3, n), np.float32)
+        _chk(lib().oracle_integrator_sample(self.handle, C.c_uint32(n), _P(A(o)), _P(A(d)), _P(A(tmax)), C.c_uint32(index_offset),
+                                            C.c_uint32(sample_index), C.c_uint32(seed), C.c_uint32(min(int(max_depth), 0xFFFFFFFF)),
+                                            C.c_uint32(rr_depth), _P(A(rgb))), "oracle_integrator_sample")
+        return rgb.T.copy()
 
     def us_acquire(self, p, seed, paths_per_ray, path_offset=0, norm_paths=None):
         n = p.n_angles * p.n_elements

@@ -1056,6 +1056,25 @@ int oracle_render_radiance(oracle_scene *s, const pbrt_camera *cam, const pbrt_f
     return PBRT_OK;
 }
 
+// Integrator.sample(scene, sampler, ray, medium, active) on caller-supplied rays (signature: CustomIntegrator.py:52; the
+// reference's body is the stub `return Color1f(0)`, the radiance estimator is Mitsuba's `path`, App. D): twin of
+// pbrt_integrator_sample.  Ray i draws from the key (index_offset + i, sample_index): with index_offset = 0, rays listed
+// in pixel order and generated with the jitter of rng4(pixel, sample_index, 0, seed) these are exactly the paths of a
+// render, so rgb[i] is the value of sample `sample_index` of pixel i.   rgb [3][n].
+int oracle_integrator_sample(oracle_scene *s, uint32_t n, const float *o, const float *d, const float *tmax,
+                             uint32_t index_offset, uint32_t sample_index, uint32_t seed, uint32_t max_depth,
+                             uint32_t rr_depth, float *rgb) {
+    if (!s || !o || !d || !tmax || !rgb || max_depth == 0) return PBRT_E_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 L = path_radiance(s->sc, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]), tmax[i],
+                             index_offset + i, sample_index, seed, max_depth, rr_depth, nullptr);
+        rgb[i] = L.x;
+        rgb[n + i] = L.y;
+        rgb[2 * n + i] = L.z;
+    }
+    return PBRT_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Ultrasound acquisition: UltraIntegrator.simulate_acquisition_parallel (CustomIntegrator.py:235-405)
 // RNG block per (ray = a*N+e, path k, bounce b): rng4(ray, k, b, seed) = (recv pick :319, s1 :337,

@@ -41,10 +41,12 @@ def _dist():
     return dist
 
 
-def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=None, device=None, sample_offset=0):
+def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=None, device=None, sample_offset=0,
+                 on_call=None):
     """Render this rank's bands into one [rows_max, W, 3] float32 torch tensor (padded to the largest
     rank).  render_band(crop, out_rows_tensor) fills a [rows, W, 3] view; the default calls the HIP
-    library and writes straight into the tensor's device memory (no PCIe traffic)."""
+    library and writes straight into the tensor's device memory (no PCIe traffic).  on_call() runs after
+    every library call (one per band; bench.py adds up the per-call statistics there)."""
     import torch
 
     sens = scene.sensors()[0]
@@ -65,6 +67,8 @@ def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=N
                 raise RuntimeError("the HIP render path needs a device tensor (torch 'cuda' == HIP on ROCm)")
             integ.render(scene, sensor=sens, seed=seed, spp=spp, crop=crop, sample_offset=sample_offset,
                          out_dev=view.data_ptr())
+            if on_call is not None:
+                on_call()
         off += rows
     return tile, layout
 
@@ -103,7 +107,8 @@ def distributed_render(scene, spp, seed=0, band_rows=64, render_band=None, devic
     return gather_film(tile, layout, W, H, rank, world, group)
 
 
-def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None, apply_pulse=None):
+def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None, apply_pulse=None,
+                        on_call=None, host_collective=False):
     """Ultrasound: every rank traces its path range into its own (already normalised) channel buffer;
     one reduce(sum) to rank 0.  acquire(offset, count, norm, out_tensor) fills the tensor; the default
     calls the HIP library on the tensor's device memory.  With pulse_model 'gaussian' rank 0 convolves the reduced
@@ -128,7 +133,11 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
                 raise RuntimeError("the HIP acquisition path needs a device tensor")
             ui._acquire(scene, ui.quirks, paths_per_ray=cnt, path_offset=off, norm_paths=paths_per_ray, seed=seed,
                         out_dev=buf.data_ptr(), pulse=False)
+            if on_call is not None:
+                on_call()
     if world > 1:
+        if host_collective:  # gloo rehearsal on one GPU: the collective runs on host tensors
+            buf = buf.cpu()
         dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
     if rank != 0:
         return None

@@ -620,7 +620,10 @@ class SamplingIntegrator(IntegratorBase):
 
     def sample(self, scene, sampler, ray, medium=None, active=True):
         """Radiance along a batch of rays: ray = dict(o [n,3], d [n,3], maxt [n] optional).
-        -> (rgb [n,3], valid mask [n], aovs [])"""
+        -> (rgb [n,3], valid mask [n], aovs [])
+        Ray i draws its random numbers from the key (sampler.index_offset + i, sampler.sample_index) under sampler.seed
+        (all 0 without a sampler): rays listed in pixel order and generated with a render's jitter ARE that render's
+        paths, so rgb[i] is sample `sample_index` of pixel i (box filter, 1 spp: the film itself)."""
         o = np.atleast_2d(np.asarray(ray["o"], dtype=np.float32))
         d = np.atleast_2d(np.asarray(ray["d"], dtype=np.float32))
         n = len(o)
@@ -629,10 +632,11 @@ class SamplingIntegrator(IntegratorBase):
         rgb = np.empty((3, n), np.float32)
         seed = getattr(sampler, "seed", 0) if sampler is not None else 0
         sidx = getattr(sampler, "sample_index", 0) if sampler is not None else 0
+        ioff = getattr(sampler, "index_offset", 0) if sampler is not None else 0
         dev = scene.device()
         md = min(int(self.max_depth) if self.max_depth >= 0 else 0xFFFFFFFF, 0xFFFFFFFF)
         dev.ctx.check(dev.ctx.lib.pbrt_integrator_sample(dev.handle, n, _capi.addr(os_), _capi.addr(ds_), _capi.addr(tm),
-                                                          0, int(sidx), int(seed), md, int(self.rr_depth),
+                                                          int(ioff), int(sidx), int(seed) & 0xFFFFFFFF, md, int(self.rr_depth),
                                                           _capi.addr(rgb)), "pbrt_integrator_sample")
         return rgb.T.copy(), np.ones(n, bool), []
 

@@ -378,6 +378,9 @@ class Sampler(Object):
         super().__init__(props)
         self.sample_count = int(props.get("sample_count", 4))
         self.seed = int(props.get("seed", 0))
+        # Integrator.sample(scene, sampler, ray): ray i draws from the key (index_offset + i, sample_index) under `seed`
+        self.sample_index = int(props.get("sample_index", 0))
+        self.index_offset = int(props.get("index_offset", 0))
 
 
 # ------------------------------------------------------------------------------------------------

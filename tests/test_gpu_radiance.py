@@ -170,18 +170,56 @@ def test_material_update_reaches_the_device(mi, ob):
     assert not np.array_equal(a, b) and np.array_equal(b, ref)
 
 
-def test_integrator_sample_on_caller_rays(mi, ob):
-    """Integrator.sample(scene, sampler, ray, ...): radiance along explicit rays == the film value those
-    rays produce (box filter, 1 spp: pixel value == its single sample)."""
-    sc = mi.load_file(scene_path("cbox.xml"), res=16, spp=1)
+def _render_rays(mi, sc, seed, s_idx):
+    """the camera rays of sample s_idx of every pixel, as render generates them: jitter = rng4(pixel, sample, 0, seed).xy
+    (the counter-based generator restated in tests/golden/ref_transcription.py), through Sensor.sample_ray"""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import ref_transcription as rt
     sens = sc.sensors()[0]
-    rng = np.random.default_rng(0)
-    pos = rng.random((500, 2), dtype=np.float32)
-    ray, w = sens.sample_ray(0.0, 0.0, pos, None)
-    rgb, valid, aovs = sc.integrator().sample(sc, None, ray)
-    assert rgb.shape == (500, 3) and np.isfinite(rgb).all() and rgb.mean() > 1e-3 and aovs == []
-    again, _, _ = sc.integrator().sample(sc, None, ray)
-    assert np.array_equal(rgb, again)
+    W, H = sens.film().size()
+    jit = np.array([rt.rng4(p, s_idx, 0, seed)[:2] for p in range(W * H)], np.float32)
+    px = np.arange(W * H, dtype=np.int64)
+    fx = (px % W).astype(np.float32) + jit[:, 0]
+    fy = (px // W).astype(np.float32) + jit[:, 1]
+    pos = np.stack([fx / np.float32(W), fy / np.float32(H)], axis=1).astype(np.float32)
+    ray, _ = sens.sample_ray(0.0, 0.0, pos, None)
+    return ray
+
+
+@pytest.mark.parametrize("scene,kw", [("cbox.xml", dict(res=24, max_depth=6)), ("cbox.xml", dict(res=16, max_depth=-1)),
+                                      ("testring.xml", dict(res=40))])
+def test_integrator_sample_on_caller_rays(mi, ob, scene, kw):
+    """Integrator.sample(scene, sampler, ray, ...) (CustomIntegrator.py:52): radiance along explicit rays.  Against its
+    oracle twin (key mode 1: keys (index_offset + i, sample_index), tmax carried by the first bounce, brute force and
+    BVH, bounded and unbounded depth), and against the film: the rays of sample s of every pixel, in pixel order, give
+    the 1-spp box-filter film of sample s bit for bit."""
+    sc = mi.load_file(scene_path(scene), spp=1, **({"rfilter": "box"} if scene == "cbox.xml" else {}), **kw)
+    if scene != "cbox.xml":
+        sc.sensors()[0].film().rfilter = mi.ReconstructionFilter(mi.Properties("box"))
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    if kw.get("max_depth") == -1:
+        integ.max_depth = 60                      # beyond any surviving path; exercises the polling of the live count
+    W, H = sens.film().size()
+    smp = mi.Sampler(mi.Properties("independent", dict(seed=9, sample_index=2)))
+    ray = _render_rays(mi, sc, 9, 2)
+    rgb, valid, aovs = integ.sample(sc, smp, ray)
+    assert rgb.shape == (W * H, 3) and np.isfinite(rgb).all() and rgb.mean() > 1e-3 and aovs == [] and valid.all()
+    osc = ob.OracleScene.from_scene(sc)
+    want = osc.integrator_sample(ray["o"], ray["d"], ray["maxt"], 0, 2, 9, integ.max_depth, integ.rr_depth)
+    assert np.array_equal(rgb, want)
+    film = integ.render(sc, seed=9, spp=1, sample_offset=2)
+    assert np.array_equal(rgb.reshape(H, W, 3), film)
+    # other keys: an index offset moves every ray to another stream; a finite maxt cuts the first segment
+    smp2 = mi.Sampler(mi.Properties("independent", dict(seed=9, sample_index=2, index_offset=1000)))
+    rgb2, _, _ = integ.sample(sc, smp2, ray)
+    assert np.array_equal(rgb2, osc.integrator_sample(ray["o"], ray["d"], ray["maxt"], 1000, 2, 9, integ.max_depth, integ.rr_depth))
+    assert not np.array_equal(rgb2, rgb)
+    short = dict(ray, maxt=np.full(W * H, 0.5, np.float32))
+    rgb3, _, _ = integ.sample(sc, smp, short)
+    assert np.array_equal(rgb3, osc.integrator_sample(short["o"], short["d"], short["maxt"], 0, 2, 9, integ.max_depth, integ.rr_depth))
+    assert rgb3.sum() < rgb.sum()
 
 
 # ---- BASELINE size (cbox 512 x 512 x 256 spp): size-independent properties ---------------------------

@@ -111,8 +111,13 @@ def test_config3_scale_properties(mi):
     b = ui._acquire(sc, ui.quirks, paths_per_ray=P, path_offset=P, seed=0)
     st = mi.default_context().stats()
     assert st["samples"] == 5 * 64 * P and np.isfinite(a).all() and np.isfinite(b).all()
-    ea, eb = float(np.abs(a).sum()), float(np.abs(b).sum())
-    assert ea > 0 and abs(ea - eb) / ea < 0.05
+    # the literal estimator multiplies by pdf = 1 / (4 |cos|) (quirks B9 / A7), which is unbounded: single paths put
+    # 10^3 times the typical echo into a bin, so plain sums of disjoint path ranges do not agree.  The energy below the
+    # 99th percentile of the non-zero bins does (oracle at P = 1024: 2.129 vs 2.116), and so does the set of bins.
+    thr = np.quantile(np.abs(a[a != 0]), 0.99)
+    ea, eb = float(np.abs(a)[np.abs(a) <= thr].sum()), float(np.abs(b)[np.abs(b) <= thr].sum())
+    assert ea > 0 and abs(ea - eb) / ea < 0.03
+    assert abs(int((a != 0).sum()) - int((b != 0).sum())) <= 0.01 * (a != 0).sum()
     again = ui._acquire(sc, ui.quirks, paths_per_ray=P, path_offset=0, seed=0)
     assert np.array_equal(again != 0, a != 0) and rel_l2(again, a) <= 1e-5
 

@@ -201,3 +201,24 @@ def test_rng_stream_is_uniform(ob, capi):
     r2 = wo[:, 0] ** 2 + wo[:, 1] ** 2
     hist, _ = np.histogram(r2, bins=10, range=(0, 1))       # concentric mapping is area preserving: r^2 uniform
     assert np.all(np.abs(hist / 5000 - 1) < 0.06)
+
+
+def test_integrator_sample_twin_equals_the_film(mi, ob):
+    """oracle_integrator_sample (twin of pbrt_integrator_sample, key mode 1) on the rays a render generates == that
+    render's 1-spp box-filter film"""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import ref_transcription as rt
+    sc = mi.load_file(scene_path("cbox.xml"), res=20, spp=1, rfilter="box")
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    W = H = 20
+    seed, s_idx = 4, 3
+    jit = np.array([rt.rng4(p, s_idx, 0, seed)[:2] for p in range(W * H)], np.float32)
+    px = np.arange(W * H)
+    pos = np.stack([((px % W).astype(np.float32) + jit[:, 0]) / np.float32(W), ((px // W).astype(np.float32) + jit[:, 1]) / np.float32(H)], axis=1)
+    o, d, tmax = ob.sensor_sample_ray(sens.camera(), pos.astype(np.float32))
+    osc = ob.OracleScene.from_scene(sc)
+    rgb = osc.integrator_sample(o, d, tmax, 0, s_idx, seed, integ.max_depth, integ.rr_depth)
+    film, _ = oracle_render(ob, sc, seed, 1, sample_offset=s_idx)
+    assert np.array_equal(rgb.reshape(H, W, 3), film) and film.mean() > 1e-3

@@ -103,7 +103,10 @@ typedef struct pbrt_emitter {
 
 #define PBRT_ACCEL_AUTO 0u  /* brute force when n_prims <= 32, LDS-resident BVH otherwise */
 #define PBRT_ACCEL_BRUTE 1u /* uniform loop over all primitives (scalar loads)            */
-#define PBRT_ACCEL_BVH 2u   /* BVH2, nodes + primitives staged into LDS per workgroup     */
+#define PBRT_ACCEL_BVH 2u   /* BVH2, nodes + primitives staged into LDS per workgroup (read through the vector caches
+                               when the image does not fit the 160 KB of LDS)                */
+#define PBRT_ACCEL_BVH_GLOBAL 3u /* BVH2 read through the vector caches even if it would fit LDS (the kernel variant of
+                               large meshes, forced: for tests and A/B runs)                 */
 
 typedef struct pbrt_scene_desc {
     uint32_t n_prims;
@@ -150,6 +153,9 @@ typedef struct pbrt_film_desc {
                                   for sample-sharded multi-GPU reduction */
 #define PBRT_FILM_NO_REPACK 2u /* diagnostic: BVH scenes, do not re-densify the live paths before bounces >= 2 \
                                   (same image either way) */
+#define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
+                                           instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
+                                           and the lone area light are left out of it) -- same film if the pruning is right */
 
 /* ---- ultrasound (acoustic) mode ----------------------------------------------------------- */
 /* Parameter block of UltraIntegrator (CustomIntegrator.py:13-48) plus the sensor transform

@@ -298,8 +298,8 @@ bool any_hit(const Scene &sc, V3 o, V3 d, float tmax) {
 // the scene's convex hull (all other geometry and every point emitter in one closed half-space of their
 // plane) -- a segment whose end points are in the hull cannot cross those (DESIGN.md "Intersection").
 // Unbounded occlusion rays (ultrasound mode, CustomIntegrator.py:324) always test every primitive.
-bool any_hit_segment(const Scene &sc, V3 o, V3 d, float tmax) {
-    if (sc.use_bvh) return any_hit(sc, o, d, tmax);
+bool any_hit_segment(const Scene &sc, V3 o, V3 d, float tmax, bool full_list = false) {
+    if (sc.use_bvh || full_list) return any_hit(sc, o, d, tmax);  // full_list: PBRT_FILM_NO_OCCLUDER_PRUNING
     for (const pbrt_prim &P : sc.occ) {
         float num, den, us, vs;
         if (prim_candidate(P, o, d, tmax, &num, &den, &us, &vs)) return true;
@@ -821,7 +821,7 @@ struct PathStats {
 };
 
 V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t kb, uint32_t seed, uint32_t max_depth,
-                 uint32_t rr_depth, PathStats *st) {
+                 uint32_t rr_depth, PathStats *st, bool no_pruning = false) {
     V3 thr = {1, 1, 1}, L = {0, 0, 0};
     float eta = 1.0f, prev_pdf = 1.0f;
     bool prev_delta = true;
@@ -866,7 +866,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
                     float sd = sqrtf(dot(sv, sv));
                     V3 sdir = sv * (1.0f / sd);
                     if (st) st->shadow++;
-                    if (!any_hit_segment(sc, so, sdir, sd * (1.0f - kShadowEps))) {
+                    if (!any_hit_segment(sc, so, sdir, sd * (1.0f - kShadowEps), no_pruning)) {
                         float mis = es.delta ? 1.0f : mis_weight(es.pdf, bpdf);
                         L = {fmaf(thr.x * f.x, es.weight.x * mis, L.x), fmaf(thr.y * f.y, es.weight.y * mis, L.y),
                              fmaf(thr.z * f.z, es.weight.z * mis, L.z)};
@@ -947,7 +947,8 @@ int oracle_scene_create(const pbrt_scene_desc *desc, oracle_scene **out) {
             return p.type > PBRT_PRIM_CONE ? PBRT_E_UNSUPPORTED : PBRT_E_INVALID;
         }
     }
-    s->sc.use_bvh = desc->accel == PBRT_ACCEL_BVH || (desc->accel == PBRT_ACCEL_AUTO && desc->n_prims > 32);
+    s->sc.use_bvh = desc->accel == PBRT_ACCEL_BVH || desc->accel == PBRT_ACCEL_BVH_GLOBAL ||
+                    (desc->accel == PBRT_ACCEL_AUTO && desc->n_prims > 32);
     if (s->sc.use_bvh)
         build_bvh(s->sc);
     else
@@ -998,7 +999,8 @@ int oracle_render_radiance(oracle_scene *s, const pbrt_camera *cam, const pbrt_f
                     V3 o, d;
                     float tmax;
                     camera_ray(*cam, px / (float)W, py / (float)H, &o, &d, &tmax);
-                    V3 L = path_radiance(sc, o, d, tmax, pix, s_idx, film->seed, film->max_depth, film->rr_depth, &st);
+                    V3 L = path_radiance(sc, o, d, tmax, pix, s_idx, film->seed, film->max_depth, film->rr_depth, &st,
+                                         (film->flags & PBRT_FILM_NO_OCCLUDER_PRUNING) != 0);
                     size_t k = (size_t)ry * rw + rx;
                     Ls[3 * k] = L.x;
                     Ls[3 * k + 1] = L.y;
@@ -1163,7 +1165,10 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     float a_resp, bpdf;
                     V3 new_dir;
                     if (M.type == PBRT_MAT_ULTRA) {
-                        UltraOut uo = ultra_core(M, p->quirks, wi, si.n, si.n, u.y, u.z, u.w); // :338
+                        // intent arithmetic (A2 off): the micro-normal's second variate comes from a second block of the
+                        // path's stream; u.w decides the roulette (:365) and must not steer the facet as well
+                        const float s1b = (p->quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, seed).x;
+                        UltraOut uo = ultra_core(M, p->quirks, wi, si.n, si.n, u.y, u.z, s1b); // :338
                         a_resp = uo.amp;
                         bpdf = uo.pdf;
                         // :165 + :358: to_world(to_local(chosen))

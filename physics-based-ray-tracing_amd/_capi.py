@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -20,10 +21,11 @@ PBRT_ABI_VERSION = 2
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
 MAT_DIFFUSE, MAT_CONDUCTOR, MAT_DIELECTRIC, MAT_ULTRA, MAT_NONE = 0, 1, 2, 3, 4
 EMIT_AREA, EMIT_POINT = 0, 1
-ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH = 0, 1, 2
+ACCEL_AUTO, ACCEL_BRUTE, ACCEL_BVH, ACCEL_BVH_GLOBAL = 0, 1, 2, 3
 FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 FILM_RAW_ACCUM = 1
 FILM_NO_REPACK = 2
+FILM_NO_OCCLUDER_PRUNING = 4
 US_MAX_ANGLES = 64
 
 USQ_DIAG_SAMPLE = 0x1
@@ -162,6 +164,28 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+def _share_the_hip_runtime_with_torch():
+    """One HIP runtime per process.  libpbrt_hip.so needs `libamdhip64.so.7`; a PyTorch-ROCm wheel bundles its own copy of
+    that runtime (torch/lib/libamdhip64.so, same soname) and looks it up by FILE name, so if the system copy under
+    /opt/rocm is mapped first a later `import torch` maps a second runtime, whose device enumeration then fails
+    ("No HIP GPUs are available") -- and device pointers could not be exchanged between the two anyway (parallel.py
+    renders into torch tensors).  If torch is installed, map ITS copy before ours: our NEEDED entry then resolves to it by
+    soname, whichever of the two is imported first.  PBRT_HIP_RUNTIME=system keeps the system copy (no torch in the
+    process)."""
+    if os.environ.get("PBRT_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # no torch, or not a ROCm build: the system runtime is the only one
+
+
 def load_library(path: str | None = None):
     """dlopen libpbrt_hip.so and bind every declared symbol.  Raises if anything is missing."""
     global _lib
@@ -172,6 +196,7 @@ def load_library(path: str | None = None):
         raise HipLibraryMissing(
             f"{p} not found: build it with `python __graft_entry__.py build` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the ray-transport hot path.")
+    _share_the_hip_runtime_with_torch()
     lib = C.CDLL(p)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

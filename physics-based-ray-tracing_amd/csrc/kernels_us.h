@@ -226,7 +226,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             V3 new_dir;
             bool ok = true;
             if (M.type == PBRT_MAT_ULTRA) {
-                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, u.w); // :338
+                // intent arithmetic (no diagonal broadcast, A2 off): the micro-normal's second variate comes from a second
+                // block of the path's stream -- u.w also decides the roulette below and must not steer the facet as well
+                const float s1b = (a.p.quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, a.seed).x;
+                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, s1b); // :338
                 a_resp = uo.amp;
                 bpdf = uo.pdf;
                 new_dir = to_world(fr, to_local(fr, uo.chosen));                       // CustomBSDF.py:165 + :358

@@ -310,7 +310,9 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     UP(upload(s, d->light_prims, d->n_light_prims, &s->ds.light_prims));
     UP(upload(s, d->light_cdf, d->n_light_prims, &s->ds.light_cdf));
     s->ds.n_light_prims = d->n_light_prims;
-    const bool want_bvh = d->accel == PBRT_ACCEL_BVH || (d->accel == PBRT_ACCEL_AUTO && d->n_prims > 32);
+    NEED(c, d->accel <= PBRT_ACCEL_BVH_GLOBAL);
+    const bool want_bvh = d->accel == PBRT_ACCEL_BVH || d->accel == PBRT_ACCEL_BVH_GLOBAL ||
+                          (d->accel == PBRT_ACCEL_AUTO && d->n_prims > 32);
     if (!want_bvh) {
         s->ds.prims = d_prims_by_id;
         s->ds.prim_ids = nullptr;
@@ -351,7 +353,7 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         s->ds.n_nodes = (uint32_t)inner.size();
         size_t lds = inner.size() * sizeof(DevNode) + (size_t)d->n_prims * (sizeof(pbrt_prim) + 4);
         // static LDS of the bounce kernels: 3 * SEG/64 dwords; keep 1 KiB of slack
-        if (c->lds_limit && lds + 1024 <= c->lds_limit) {
+        if (c->lds_limit && lds + 1024 <= c->lds_limit && d->accel != PBRT_ACCEL_BVH_GLOBAL) {
             s->accel_kernel = ACCEL_K_BVH_LDS;
             s->lds_bytes = (uint32_t)((lds + 15) & ~size_t(15));
         } else {
@@ -495,6 +497,10 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         const uint32_t sc = std::min(s_pass, f->spp - s0);
         RadArgs a{};
         a.sc = s->ds;
+        if ((f->flags & PBRT_FILM_NO_OCCLUDER_PRUNING) && a.sc.occ_prims) {  // diagnostic: shadow segments walk every primitive
+            a.sc.occ_prims = a.sc.prims;
+            a.sc.n_occ = a.sc.n_prims;
+        }
         a.cam = *cam;
         a.Lhome = Lhome;
         a.stats = segstats;
@@ -788,6 +794,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
     NEED(c, (uint64_t)p->n_angles * p->n_elements * p->time_samples < 0xffffffffull);  // channel index is 32-bit (echo bins)
     NEED(c, p->max_depth > 0 && ppr > 0 && p->sound_speed > 0 && p->fs > 0);
+    NEED(c, p->max_depth < 0x40000000u);  // RNG block = bounce index; bit 30 marks a path's second block of a bounce
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;

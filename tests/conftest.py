@@ -44,9 +44,9 @@ def scene_path(name):
     return os.path.join(SCENES, name)
 
 
-def oracle_render(ob, scene, seed, spp, crop=None, sample_offset=0, raw=False, n_threads=8, accel=None):
+def oracle_render(ob, scene, seed, spp, crop=None, sample_offset=0, raw=False, n_threads=8, accel=None, flags=0):
     integ, sens = scene.integrator(), scene.sensors()[0]
-    fd = integ._film_desc(scene, sens, seed, spp, crop, sample_offset, raw)
+    fd = integ._film_desc(scene, sens, seed, spp, crop, sample_offset, raw, flags=flags)
     osc = ob.OracleScene.from_scene(scene, accel)
     img = osc.render(sens.camera(), fd, n_threads=n_threads)
     return img, osc.last_stats

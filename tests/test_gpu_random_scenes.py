@@ -103,3 +103,35 @@ def test_mesh_larger_than_lds_takes_the_global_bvh_kernels(mi, ob, capi, tmp_pat
     assert np.array_equal(img, ref) and img.mean() > 0.01
     big = integ.render(sc, seed=9, spp=4, pass_paths=3000)            # several passes, repack between bounces
     assert np.array_equal(big, img)
+
+
+@pytest.mark.parametrize("accel", ["auto", "bvh", "bvh_global"])
+def test_cbox_with_the_reference_boxes(mi, ob, capi, accel):
+    """SURVEY f-4: scenes/meshes/cbox_largebox.obj + cbox_smallbox.obj in the Cornell room (tests/scenes/cbox_boxes.xml),
+    64 x 64 x 4 spp, through the brute-force kernel (22 primitives), the LDS-resident BVH and the BVH read through the
+    vector caches (PBRT_ACCEL_BVH_GLOBAL: the kernel variant of meshes larger than LDS) -- each bit-exact against the
+    oracle with the same accelerator semantics (DESIGN D9)"""
+    sc = mi.load_file(scene_path("cbox_boxes.xml"), res=64, spp=4)
+    sc.accel = {"auto": capi.ACCEL_AUTO, "bvh": capi.ACCEL_BVH, "bvh_global": capi.ACCEL_BVH_GLOBAL}[accel]
+    img = mi.render(sc, seed=2)
+    ref, _ = oracle_render(ob, sc, 2, 4)
+    assert np.array_equal(img, ref) and img.mean() > 0.05
+    if accel != "auto":   # the two accelerators see the same surfaces: films agree up to tie-breaking on shared edges
+        sc2 = mi.load_file(scene_path("cbox_boxes.xml"), res=64, spp=4)
+        assert np.mean(np.abs(mi.render(sc2, seed=2) - img)) < 1e-3
+
+
+@pytest.mark.parametrize("bulb", [[0.3, 0.2, 0.5], [3.0, 0.5, 0.0], [0.0, 4.0, 0.0]])
+def test_occluder_pruning_changes_nothing_on_the_device(mi, ob, capi, bulb):
+    """DESIGN D11 on the HIP side: same film with the occluder list and with shadow segments that walk every primitive,
+    for point lights inside and outside the room; both equal the oracle"""
+    from test_oracle_transport import _hull_scene
+    sc = _hull_scene(mi, bulb)
+    integ = sc.integrator()
+    a = integ.render(sc, seed=3, spp=4)
+    b = integ.render(sc, seed=3, spp=4, flags=capi.FILM_NO_OCCLUDER_PRUNING)
+    ref, _ = oracle_render(ob, sc, 3, 4)
+    assert np.array_equal(a, b) and np.array_equal(a, ref)
+    cb = mi.load_file(scene_path("cbox.xml"), res=64, spp=8)
+    assert np.array_equal(cb.integrator().render(cb, seed=1, spp=8),
+                          cb.integrator().render(cb, seed=1, spp=8, flags=capi.FILM_NO_OCCLUDER_PRUNING))

@@ -222,3 +222,42 @@ def test_integrator_sample_twin_equals_the_film(mi, ob):
     rgb = osc.integrator_sample(o, d, tmax, 0, s_idx, seed, integ.max_depth, integ.rr_depth)
     film, _ = oracle_render(ob, sc, seed, 1, sample_offset=s_idx)
     assert np.array_equal(rgb.reshape(H, W, 3), film) and film.mean() > 1e-3
+
+
+def _hull_scene(mi, bulb_pos):
+    """a small room (open front) with a ball, an area light inside and a point light at bulb_pos"""
+    T = mi.ScalarTransform4f
+    dif = lambda r, g, b: {"type": "diffuse", "reflectance": {"type": "rgb", "value": [r, g, b]}}
+    return mi.load_dict({
+        "type": "scene", "integrator": {"type": "path", "max_depth": 4},
+        "sensor": {"type": "perspective", "fov": 45, "near_clip": 0.01, "far_clip": 50,
+                   "to_world": T().look_at([0, 0.2, 3.6], [0, 0, 0], [0, 1, 0]),
+                   "film": {"type": "hdrfilm", "width": 40, "height": 40, "rfilter": {"type": "tent"}},
+                   "sampler": {"type": "independent", "sample_count": 4}},
+        "floor": {"type": "rectangle", "to_world": T().translate([0, -1, 0]).rotate([1, 0, 0], -90), "bsdf": dif(.7, .7, .7)},
+        "ceil": {"type": "rectangle", "to_world": T().translate([0, 1, 0]).rotate([1, 0, 0], 90), "bsdf": dif(.7, .7, .7)},
+        "back": {"type": "rectangle", "to_world": T().translate([0, 0, -1]), "bsdf": dif(.7, .7, .7)},
+        "left": {"type": "rectangle", "to_world": T().translate([-1, 0, 0]).rotate([0, 1, 0], 90), "bsdf": dif(.2, .6, .2)},
+        "right": {"type": "rectangle", "to_world": T().translate([1, 0, 0]).rotate([0, 1, 0], -90), "bsdf": dif(.6, .2, .2)},
+        "blocker": {"type": "rectangle", "to_world": T().translate([0.2, -0.3, 0.1]).rotate([0, 1, 0], 30).scale(0.35), "bsdf": dif(.5, .5, .8)},
+        "ball": {"type": "sphere", "center": [-0.4, -0.6, 0.2], "radius": 0.4, "bsdf": dif(.8, .8, .3)},
+        "lamp": {"type": "rectangle", "to_world": T().translate([0, 0.98, 0]).rotate([1, 0, 0], 90).scale(0.3),
+                 "emitter": {"type": "area", "radiance": {"type": "rgb", "value": [6, 6, 6]}}},
+        "bulb": {"type": "point", "position": bulb_pos, "intensity": {"type": "rgb", "value": [8, 8, 8]}},
+    })
+
+
+@pytest.mark.parametrize("bulb", [[0.3, 0.2, 0.5], [0.0, 0.5, 2.5], [3.0, 0.5, 0.0], [0.0, 4.0, 0.0]])
+def test_occluder_pruning_changes_nothing(mi, ob, capi, bulb):
+    """DESIGN D11: shadow segments of brute-force scenes skip the primitives on the scene's convex hull.  A point light
+    inside the room, in front of the open side, and OUTSIDE the room behind a wall / above the ceiling (then the wall is
+    not on the hull of geometry + emitters and must stay an occluder): the film with the pruning equals the film whose
+    shadow segments walk every primitive (PBRT_FILM_NO_OCCLUDER_PRUNING)."""
+    sc = _hull_scene(mi, bulb)
+    a, _ = oracle_render(ob, sc, 3, 4)
+    b, _ = oracle_render(ob, sc, 3, 4, flags=capi.FILM_NO_OCCLUDER_PRUNING)
+    assert np.array_equal(a, b) and a.mean() > 0.05
+    cb = mi.load_file(scene_path("cbox.xml"), res=40, spp=4)
+    a, _ = oracle_render(ob, cb, 1, 4)
+    b, _ = oracle_render(ob, cb, 1, 4, flags=capi.FILM_NO_OCCLUDER_PRUNING)
+    assert np.array_equal(a, b)

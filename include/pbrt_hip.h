@@ -153,6 +153,10 @@ typedef struct pbrt_film_desc {
                                   for sample-sharded multi-GPU reduction */
 #define PBRT_FILM_NO_REPACK 2u /* diagnostic: BVH scenes, do not re-densify the live paths before bounces >= 2 \
                                   (same image either way) */
+#define PBRT_FILM_FUSE_PLAN_SET 0x80u /* bits 8..15 of flags hold the fuse plan: bit d set = the launch at depth d walks bounce d \
+                                        AND d + 1 of its paths in registers (brute-force kernels; same film either way). \
+                                        Unset: the library's default plan.  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce */
+#define PBRT_FILM_FUSE_PLAN(mask) (PBRT_FILM_FUSE_PLAN_SET | (((mask) & 0xffu) << 8))
 #define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
                                            instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
                                            and the lone area light are left out of it) -- same film if the pruning is right */

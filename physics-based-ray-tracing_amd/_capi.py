@@ -26,6 +26,13 @@ FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 FILM_RAW_ACCUM = 1
 FILM_NO_REPACK = 2
 FILM_NO_OCCLUDER_PRUNING = 4
+FILM_FUSE_PLAN_SET = 0x80
+
+
+def film_fuse_plan(mask: int) -> int:
+    """flags value selecting which depths start a two-bounce launch (include/pbrt_hip.h PBRT_FILM_FUSE_PLAN)"""
+    return FILM_FUSE_PLAN_SET | ((int(mask) & 0xFF) << 8)
+
 US_MAX_ANGLES = 64
 
 USQ_DIAG_SAMPLE = 0x1

@@ -255,13 +255,20 @@ DEV void stage_scene_lds(const DevScene &sc, uint32_t *lds, LdsScene *ls) {
     __syncthreads();
 }
 
-template <bool FIRST, int ACCEL>
-__global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
+// NB: bounces walked by one launch (1 or 2; brute-force kernels only).  With NB = 2 a path that survives its first bounce
+// of the launch goes straight on in registers -- no state write, no compaction, no state read in between -- and the
+// lanes whose paths ended idle through the second bounce (87 % / 83 % of the lanes stay busy at depths 0 / 2 of the
+// Cornell box, 20 % at depth 4, so the host fuses the early pairs only: rad_fuse_plan).  Same arithmetic per bounce, same
+// RNG keys: the film does not change.  The loop costs registers, so these variants take the 128-VGPR budget.
+template <bool FIRST, int ACCEL, int NB = 1>
+__global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? 4 : seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
+    static_assert(NB == 1 || ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "fused bounces: brute-force kernels only");
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];  // double-buffered across the chunk loop: one barrier per chunk
     __shared__ uint32_t wave_seg[2][SEG / 64];
     __shared__ uint32_t wave_shd[2][SEG / 64];
+    __shared__ uint32_t wave_mid[2][NB > 1 ? SEG / 64 : 1];  // NB = 2: paths that went on to the launch's second bounce
 
     const uint32_t seg = blockIdx.x;  // region index
     const uint32_t tid = threadIdx.x;
@@ -318,6 +325,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
             wave_tot[0][tid >> 6] = 0;
             wave_seg[0][tid >> 6] = 0;
             wave_shd[0][tid >> 6] = 0;
+            if (NB > 1) wave_mid[0][tid >> 6] = 0;
         }
         // s_endpgm behind the compiler's back keeps the kernel single-exit for the structurizer
         const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u;
@@ -339,7 +347,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
     const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
     uint32_t out_off = 0;      // survivors written so far (front of this region of the `out` state)
-    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0;
+    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0, mid_acc = 0;
     // the region's live paths sit compacted at its front: walk them SEG at a time; dead slots cost nothing
     for (uint32_t it0 = 0; it0 < (REGION > SEG ? cnt_in : 1u); it0 += CH) {  // single trip when REGION == SEG
     if (DYN) {  // take the next 64-path chunk of the region from the workgroup's queue
@@ -384,7 +392,21 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
     }
     // shading tables -> LDS, behind the state loads so that the two memory round trips overlap
     if (ACCEL == ACCEL_K_BRUTE && !FIRST && !PERWAVE && it0 == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
-    if (alive) {
+    if (alive && !FIRST) path_key<TILED>(a, home, &ka, &kb, &px, &py);
+    bool live = alive;                        // the lane still carries a path
+    uint32_t nseg_w = 0, nshd_w = 0, nmid_w = 0;  // wave-uniform counts over the launch's bounces
+#pragma unroll 1
+    for (uint32_t bounce = 0; bounce < (uint32_t)NB; ++bounce) {
+    const uint32_t depth = a.depth + bounce;
+    if (NB > 1 && bounce > 0) {
+        if (depth >= a.max_depth) break;      // uniform
+        nmid_w += (uint32_t)__popcll(__ballot(live));
+        tmax = K_INF;
+    }
+    did_seg = false;
+    did_shadow = false;
+    survive = false;
+    if (live) {
 #ifdef PBRT_PROBE_EXTRA_VALU  // diagnostic builds only: N dependent full-rate VALU instructions per live wave-bounce
         {
             float probe = o.x;
@@ -393,8 +415,6 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
             if (probe == 12345.678f) o.x = probe;  // never true; keeps the chain alive
         }
 #endif
-        if (!FIRST) path_key<TILED>(a, home, &ka, &kb, &px, &py);
-        const uint32_t depth = a.depth;
         const uint32_t nE = a.sc.n_emitters;
         Hit h;
         if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, tmax, &h)) {
@@ -484,29 +504,33 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
             __builtin_amdgcn_raw_buffer_store_b128(rec, r_L, home * 16u, 0, 0);
         }
     }
+    live = survive;
+    nseg_w += (uint32_t)__popcll(__ballot(did_seg));
+    nshd_w += (uint32_t)__popcll(__ballot(did_shadow));
+    }  // bounces of this launch
     // ---- segment-local stream compaction: ballot + mbcnt inside the wave, LDS scan across waves
     const uint32_t wid = tid >> 6;
     const unsigned long long bal = __ballot(survive);
     const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-    const unsigned long long bseg = __ballot(did_seg), bshd = __ballot(did_shadow);
     uint32_t off = 0, total = 0;
     if (DYN) {  // reserve the survivors' slots in the region with one returning LDS atomic per wave and chunk
         const uint32_t cnt_w = (uint32_t)__popcll(bal);
         uint32_t got = 0;
         if ((tid & 63u) == 0 && cnt_w) got = atomicAdd(&q_out, cnt_w);
         off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-        ns_acc += (uint32_t)__popcll(bseg);
-        nh_acc += (uint32_t)__popcll(bshd);
+        ns_acc += nseg_w;
+        nh_acc += nshd_w;
         live_acc += (uint32_t)__popcll(__ballot(alive));
     } else if (WP) {  // the wave packs its own survivors behind its own cursor: no LDS, no barrier
         total = (uint32_t)__popcll(bal);
-        ns_acc += (uint32_t)__popcll(bseg);
-        nh_acc += (uint32_t)__popcll(bshd);
+        ns_acc += nseg_w;
+        nh_acc += nshd_w;
     } else {
     if ((tid & 63) == 0) {
         wave_tot[buf][wid] = (uint32_t)__popcll(bal);
-        wave_seg[buf][wid] = (uint32_t)__popcll(bseg);
-        wave_shd[buf][wid] = (uint32_t)__popcll(bshd);
+        wave_seg[buf][wid] = nseg_w;
+        wave_shd[buf][wid] = nshd_w;
+        if (NB > 1) wave_mid[buf][wid] = nmid_w;
     }
     __syncthreads();
     // exclusive scan over the waves' survivor counts on the scalar unit: one LDS read per lane, then
@@ -544,6 +568,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         for (uint32_t w = 0; w < SEG / 64; ++w) {
             ns_acc += wave_seg[buf][w];
             nh_acc += wave_shd[buf][w];
+            if (NB > 1) mid_acc += wave_mid[buf][w];
         }
     }
     }  // chunk loop
@@ -569,6 +594,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), seg_waves_per_eu(ACCEL)) void k
         row[0] += ns_acc;
         row[stride] += nh_acc;
         row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
+        if (NB > 1) row[(2 + min(a.depth + 1, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += mid_acc;
     }
 }
 

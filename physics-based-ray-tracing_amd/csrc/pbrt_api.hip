@@ -387,15 +387,27 @@ int pbrt_scene_destroy(pbrt_scene *s) {
 // ------------------------------------------------------------------------------------------------
 // radiance mode driver
 // ------------------------------------------------------------------------------------------------
+// Depths at which a launch of the brute-force kernels walks two bounces (bit d: bounces d and d + 1).  Measured on the
+// Cornell box; pbrt_film_desc.flags can override it per call (PBRT_FILM_FUSE_PLAN).
+#ifndef PBRT_DEFAULT_FUSE_PLAN
+#define PBRT_DEFAULT_FUSE_PLAN 0x1u
+#endif
+// nb: bounces this launch walks (2: the fused variants of the brute-force kernels, kernels_radiance.h)
 template <bool FIRST>
-static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg) {
+static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            if (nb == 2)
+                hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BRUTE_BIG:
-            hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            if (nb == 2)
+                hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BVH_GLOBAL:
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
@@ -422,14 +434,18 @@ static int set_lds_attr(pbrt_scene *s) {
 }
 
 // Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
+// A launch that walks two bounces (fuse plan bit d) keeps its paths in registers between them: the survivors of bounce d
+// are neither written nor read back, only the survivors of bounce d + 1 are.
 static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, uint64_t samples, uint64_t film_px,
-                                 uint32_t passes, uint64_t *total, uint64_t *bounce) {
+                                 uint32_t passes, uint32_t fuse_plan, uint32_t max_depth, uint64_t *total, uint64_t *bounce) {
     uint64_t b = 0;
-    for (uint32_t d = 0; d < nd; ++d) {
-        uint64_t in = live[d], next = (d + 1 < nd) ? live[d + 1] : 0;
+    for (uint32_t d = 0; d < nd;) {
+        const uint32_t nb = (d < 8 && ((fuse_plan >> d) & 1u) && d + 1 < max_depth && d + 1 < nd) ? 2u : 1u;
+        uint64_t in = live[d], next = (d + nb < nd) ? live[d + nb] : 0;
         if (d > 0) b += in * (N_STATE * 4);  // state read
         b += next * (N_STATE * 4);            // compacted survivors written
-        b += (in - next) * 12;                // radiance of the paths that ended
+        b += (in - next) * 12;                // radiance of the paths that ended (at either bounce of the launch)
+        d += nb;
     }
     *bounce = b;
     *total = b + samples * 12 /* film gather reads Lhome once */ + film_px * 32ull * passes /* accumulator RMW */ +
@@ -528,7 +544,12 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         const uint32_t nseg_pass = div_up(a.n_paths, REGION);
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
-        for (uint32_t depth = 0; depth < f->max_depth; ++depth) {
+        const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
+        const uint32_t fuse_plan = (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN;
+        for (uint32_t depth = 0; depth < f->max_depth;) {
+            // bounces this launch walks: 2 at the depths of the fuse plan (brute-force kernels; the last bounce of a
+            // path only looks for emitters, so it is never worth a launch slot of its own either)
+            const uint32_t nb = (brute && depth < 8 && ((fuse_plan >> depth) & 1u) && depth + 1 < f->max_depth) ? 2u : 1u;
             a.depth = depth;
             a.in = in;
             a.out = out;
@@ -555,15 +576,17 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 HIPCHK(c, hipEventRecord(e0, st));
             }
             if (depth == 0)
-                launch_bounce<true>(s, a, nseg_pass);
+                launch_bounce<true>(s, a, nseg_pass, nb);
             else
-                launch_bounce<false>(s, a, nseg_pass);
+                launch_bounce<false>(s, a, nseg_pass, nb);
             HIPCHK(c, hipGetLastError());
             ++launches;
             std::swap(in, out);
             std::swap(sin, sout);
+            const uint32_t depth_before = depth;
+            depth += nb;
             // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces
-            if (f->max_depth > 32 && (depth & 7) == 7) {
+            if (f->max_depth > 32 && (depth >> 3) != (depth_before >> 3)) {
                 std::vector<uint32_t> cnt(n_own);
                 HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)n_own * 4, hipMemcpyDeviceToHost, st));
                 HIPCHK(c, hipStreamSynchronize(st));
@@ -639,7 +662,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     S.passes = passes;
     uint64_t tot, bb;
     for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
-    radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, &tot, &bb);
+    const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
+    const uint32_t plan = !brute_k ? 0u : ((f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN);
+    radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth, &tot, &bb);
     S.model_bytes = tot;
     S.bounce_model_bytes = bb;
     return PBRT_OK;

@@ -299,3 +299,28 @@ def test_bvh_repack_with_a_short_last_pass(mi, ob, capi):
     band = (0, 160, 320, 16)
     ref, _ = oracle_render(ob, sc, 3, 13, crop=band)
     assert np.array_equal(short[160:176], ref)
+
+
+@pytest.mark.parametrize("scene,kw", [("cbox.xml", dict(res=48, max_depth=6)), ("cbox.xml", dict(res=32, max_depth=5)),
+                                      ("cbox.xml", dict(res=24, max_depth=2)), ("cone_room.xml", dict(res=32))])
+def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
+    """a launch of the brute-force kernels may walk two bounces of its paths in registers (include/pbrt_hip.h
+    PBRT_FILM_FUSE_PLAN: bit d = the launch at depth d also does bounce d + 1): every plan gives the film of one launch per
+    bounce, bit for bit, the same per-depth path counts, and the oracle's film -- even and odd depth budgets, a budget
+    of 2 (nothing left to fuse after the emitter lookup), both brute-force kernel variants (cone_room: the _BIG one)"""
+    sc = mi.load_file(scene_path(scene), spp=6, **kw)
+    integ = sc.integrator()
+    ctx = mi.default_context()
+    base = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(0))
+    st0 = ctx.stats()
+    ref, _ = oracle_render(ob, sc, 5, 6)
+    assert np.array_equal(base, ref)
+    for plan in (0x1, 0x2, 0x4, 0x5, 0xA, 0x15, 0xFF):
+        img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(plan))
+        st = ctx.stats()
+        assert np.array_equal(img, base), hex(plan)
+        assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+        assert st["bounce_launches"] <= st0["bounce_launches"] and st["bounce_model_bytes"] <= st0["bounce_model_bytes"]
+    assert np.array_equal(integ.render(sc, seed=5, spp=6), base)          # the library's default plan
+    # passes: a short last pass and the fused first launch
+    assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)

@@ -4,6 +4,8 @@ bit for bit.  Seeds are fixed: the cases are reproducible."""
 import numpy as np
 import pytest
 
+from conftest import oracle_render, scene_path
+
 pytestmark = pytest.mark.gpu
 
 

@@ -1,7 +1,15 @@
-"""copy the judged summaries of gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into profiles/ and refresh pmc_traffic.json"""
+"""copy the judged summaries of gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into profiles/ and refresh the entry of
+profiles/pmc_traffic.json for one bench config.   usage: python tools/update_profiles.py <tag> <config> [fetch_factor]
+fetch_factor: known bytes / (FETCH_SIZE * 1024) measured by tools/pmc_calibrate.sh on k_bounce's own state access pattern
+(default 2.0, the guide's factor for wide streaming reads)."""
 import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+sys.path.insert(0, root)
+from bench import kernel_source_hash  # noqa: E402
+tag = sys.argv[1]
+config = sys.argv[2]
+fetch_factor = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
+write_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, f"{tag}_rocprofv3_summary.txt"))
@@ -9,16 +17,17 @@ shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{tag}_rocprof
 ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if ks:
     shutil.copy(max(ks, key=os.path.getmtime), os.path.join(dst, f"{tag}_kernel_stats.csv"))
-b = os.path.join(root, "gpurun_out", "bench_n1.json")
+b = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(b):
-    shutil.copy(b, os.path.join(dst, f"{tag}_bench_n1.json"))
+    shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+kernel = "k_us_bounce" if config.startswith("us_") else "k_bounce"
 
 
 def per_dispatch(sub, ctr):
     f = max(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)  # newest run
     tot, n = {}, {}
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != ctr or "k_bounce" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != ctr or kernel + "<" not in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
@@ -28,14 +37,19 @@ def per_dispatch(sub, ctr):
 
 fetch, nf = per_dispatch("pmc_fetch", "FETCH_SIZE")
 write, nw = per_dispatch("pmc_write", "WRITE_SIZE")
-num = sum((2 * fetch[k] + write[k]) * 1024 * nf[k] for k in fetch)
-out = {
-    "k_bounce_hbm_bytes_per_launch": round(num / sum(nf.values())),
-    "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 0 "
-           "--no-cpu-baseline` (tools/profile_bench.sh); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch (gfx950 FETCH_SIZE "
-           "counts half of coalesced streaming reads, MI355X_MICROARCH.md 'HBM'), averaged over the k_bounce<true,0> and "
-           "k_bounce<false,0> dispatches",
-    "fetch_kib_per_dispatch": fetch, "write_kib_per_dispatch": write, "round": int(tag[1:3]) if tag[1:3].isdigit() else None,
+num = sum((fetch_factor * fetch[k] + write_factor * write.get(k, 0.0)) * 1024 * nf[k] for k in fetch)
+path = os.path.join(dst, "pmc_traffic.json")
+allrec = json.load(open(path)) if os.path.exists(path) else {}
+if "k_bounce_hbm_bytes_per_launch" in allrec:   # round-1 layout: keep it under its own key
+    allrec = {"r01_cbox": allrec}
+allrec[config] = {
+    "kernel": kernel, "hbm_bytes_per_launch": round(num / max(sum(nf.values()), 1)), "kernel_source_sha16": kernel_source_hash(),
+    "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --config {config} --steps 2 "
+           f"--warmup 0 --no-cpu-baseline` (tools/profile_bench.sh {tag}); bytes = ({fetch_factor:g}*FETCH_SIZE + {write_factor:g}*WRITE_SIZE)*1024 "
+           f"per dispatch, averaged over the {kernel} dispatches; FETCH factor: tools/pmc_calibrate.sh on the kernel's own "
+           f"4-B-per-lane tiled row pattern (profiles/{tag.split('_')[0]}_pmc_calibration.json)",
+    "fetch_factor": fetch_factor, "write_factor": write_factor,
+    "fetch_kib_per_dispatch": fetch, "write_kib_per_dispatch": write, "dispatches": nf, "tag": tag,
 }
-json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1))
+json.dump(allrec, open(path, "w"), indent=1)
+print(json.dumps(allrec[config], indent=1))

@@ -157,6 +157,10 @@ typedef struct pbrt_film_desc {
                                         AND d + 1 of its paths in registers (brute-force kernels; same film either way). \
                                         Unset: the library's default plan.  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce */
 #define PBRT_FILM_FUSE_PLAN(mask) (PBRT_FILM_FUSE_PLAN_SET | (((mask) & 0xffu) << 8))
+#define PBRT_FILM_WALK_SET 0x10000u /* bits 17..24 of flags hold the depth from which ONE launch walks every remaining bounce of a \
+                                       pass (brute-force kernels: the workgroup that owns a segment carries its survivors on; \
+                                       0 = one launch per pass, 0xff = never).  Unset: the library's default.  Same film either way */
+#define PBRT_FILM_WALK_FROM(d) (PBRT_FILM_WALK_SET | (((d) & 0xffu) << 17))
 #define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
                                            instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
                                            and the lone area light are left out of it) -- same film if the pruning is right */

@@ -29,6 +29,14 @@ FILM_NO_OCCLUDER_PRUNING = 4
 FILM_FUSE_PLAN_SET = 0x80
 
 
+FILM_WALK_SET = 0x10000
+
+
+def film_walk_from(depth: int) -> int:
+    """flags value: from this depth on ONE launch walks every remaining bounce (0xff: never; include/pbrt_hip.h PBRT_FILM_WALK_FROM)"""
+    return FILM_WALK_SET | ((int(depth) & 0xFF) << 17)
+
+
 def film_fuse_plan(mask: int) -> int:
     """flags value selecting which depths start a two-bounce launch (include/pbrt_hip.h PBRT_FILM_FUSE_PLAN)"""
     return FILM_FUSE_PLAN_SET | ((int(mask) & 0xFF) << 8)

@@ -255,6 +255,105 @@ DEV void stage_scene_lds(const DevScene &sc, uint32_t *lds, LdsScene *ls) {
     __syncthreads();
 }
 
+// One bounce of one path (the body shared by k_bounce and k_walk): closest hit, emission + MIS, next-event estimation with
+// its shadow segment, BSDF sample, Russian roulette.  Returns whether the path goes on; a path that ends writes its
+// radiance to Lhome[home].
+template <int ACCEL>
+DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsrc r_L, uint32_t depth, uint32_t ka, uint32_t kb,
+                     uint32_t home, float tmax, V3 &o, V3 &d, V3 &thr, V3 &L, float &eta, float &prev_pdf, bool &did_seg,
+                     bool &did_shadow) {
+    bool survive = false;
+        const uint32_t nE = a.sc.n_emitters;
+        Hit h;
+        if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, tmax, &h)) {
+            did_seg = true;
+            const pbrt_prim &P = tb.prims_by_slot[h.slot];
+            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
+            const int32_t emitter = P.emitter;
+            const uint32_t mat_id = P.material;
+            // ---- direct emission (one-sided area emitters), MIS against emitter sampling
+            if (emitter >= 0) {
+                const pbrt_emitter &E = tb.emitters[emitter];
+                float cosl = -dot(si.n, d);
+                if (cosl > 0.0f) {
+                    float w = 1.0f;
+                    if (prev_pdf >= 0.0f) {
+                        float pdf_em = (h.t * h.t) / (cosl * E.area * (float)nE);
+                        w = mis_weight(prev_pdf, pdf_em);
+                    }
+                    L = {fma_(thr.x * E.radiance[0], w, L.x), fma_(thr.y * E.radiance[1], w, L.y),
+                         fma_(thr.z * E.radiance[2], w, L.z)};
+                }
+            }
+            if (depth + 1 < a.max_depth) {
+                const pbrt_material M = tb.mats[mat_id];
+                Frame fr = make_frame(si.n);
+                V3 wi = to_local(fr, -d);
+                // ---- emitter sampling (next-event estimation) + shadow ray
+#ifdef PBRT_ABLATE_NEE  // diagnostic builds only (tools/ablate.sh): never defined in the shipped library
+                if (false) {
+#else
+                if (M.type == PBRT_MAT_DIFFUSE && nE > 0) {
+#endif
+                    F4 u = rng4(ka, kb, 1 + 2 * depth, a.seed);
+                    ESample es = sample_emitter(tb, si.p, u);
+                    if (es.valid) {
+                        V3 wo = to_local(fr, es.d);
+                        V3 f;
+                        float bpdf;
+                        bsdf_eval_pdf(M, wi, wo, &f, &bpdf);
+                        if (bpdf > 0.0f) {
+                            V3 so = offset_origin(si.p, si.n, es.d);
+                            V3 sv = es.q - so;
+                            float sd = sqrtf(dot(sv, sv));
+                            V3 sdir = sv * (1.0f / sd);
+                            did_shadow = true;
+                            Hit hs;
+#ifdef PBRT_ABLATE_SHADOW
+                            if (sd > 0.0f) {
+#else
+                            if (!scene_intersect<ACCEL, true, true>(a.sc, ls, so, sdir, sd * (1.0f - K_SHADOW_EPS), &hs)) {
+#endif
+                                float mis = es.delta ? 1.0f : mis_weight(es.pdf, bpdf);
+                                L = {fma_(thr.x * f.x, es.weight.x * mis, L.x), fma_(thr.y * f.y, es.weight.y * mis, L.y),
+                                     fma_(thr.z * f.z, es.weight.z * mis, L.z)};
+                            }
+                        }
+                    }
+                }
+                // ---- BSDF sampling, continuation ray, Russian roulette
+                F4 ub = rng4(ka, kb, 2 + 2 * depth, a.seed);
+                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
+                if (bs.valid) {
+                    thr = thr * bs.weight;
+                    eta *= bs.eta;
+                    V3 nd = to_world(fr, bs.wo);
+                    if (M.type == PBRT_MAT_ULTRA) nd = normalize(nd);
+                    o = offset_origin(si.p, si.n, nd);
+                    d = nd;
+                    prev_pdf = bs.delta ? -1.0f : bs.pdf;
+                    float tm = max3(thr);
+                    survive = true;
+                    if (depth + 1 >= a.rr_depth) {
+                        float q = fminf(tm * eta * eta, 0.95f);
+                        float rq = 1.0f / q;
+                        thr = thr * rq;
+                        if (!(ub.w < q)) survive = false;
+                    }
+                    if (tm == 0.0f) survive = false;
+                }
+            }
+        }
+        if (!survive) {
+            // one 16-byte record per finished path: three 4-byte row stores at a scattered `home` cost three
+            // 32-byte HBM sectors (measured: k_bounce WRITE_SIZE 1.23 x algorithmic), one dwordx4 store costs one
+            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+            const u32x4 rec = {__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(rec, r_L, home * 16u, 0, 0);
+        }
+    return survive;
+}
+
 // NB: bounces walked by one launch (1 or 2; brute-force kernels only).  With NB = 2 a path that survives its first bounce
 // of the launch goes straight on in registers -- no state write, no compaction, no state read in between -- and the
 // lanes whose paths ended idle through the second bounce (87 % / 83 % of the lanes stay busy at depths 0 / 2 of the
@@ -415,94 +514,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? 4 : seg_waves_per_eu(A
             if (probe == 12345.678f) o.x = probe;  // never true; keeps the chain alive
         }
 #endif
-        const uint32_t nE = a.sc.n_emitters;
-        Hit h;
-        if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, tmax, &h)) {
-            did_seg = true;
-            const pbrt_prim &P = tb.prims_by_slot[h.slot];
-            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
-            const int32_t emitter = P.emitter;
-            const uint32_t mat_id = P.material;
-            // ---- direct emission (one-sided area emitters), MIS against emitter sampling
-            if (emitter >= 0) {
-                const pbrt_emitter &E = tb.emitters[emitter];
-                float cosl = -dot(si.n, d);
-                if (cosl > 0.0f) {
-                    float w = 1.0f;
-                    if (prev_pdf >= 0.0f) {
-                        float pdf_em = (h.t * h.t) / (cosl * E.area * (float)nE);
-                        w = mis_weight(prev_pdf, pdf_em);
-                    }
-                    L = {fma_(thr.x * E.radiance[0], w, L.x), fma_(thr.y * E.radiance[1], w, L.y),
-                         fma_(thr.z * E.radiance[2], w, L.z)};
-                }
-            }
-            if (depth + 1 < a.max_depth) {
-                const pbrt_material M = tb.mats[mat_id];
-                Frame fr = make_frame(si.n);
-                V3 wi = to_local(fr, -d);
-                // ---- emitter sampling (next-event estimation) + shadow ray
-#ifdef PBRT_ABLATE_NEE  // diagnostic builds only (tools/ablate.sh): never defined in the shipped library
-                if (false) {
-#else
-                if (M.type == PBRT_MAT_DIFFUSE && nE > 0) {
-#endif
-                    F4 u = rng4(ka, kb, 1 + 2 * depth, a.seed);
-                    ESample es = sample_emitter(tb, si.p, u);
-                    if (es.valid) {
-                        V3 wo = to_local(fr, es.d);
-                        V3 f;
-                        float bpdf;
-                        bsdf_eval_pdf(M, wi, wo, &f, &bpdf);
-                        if (bpdf > 0.0f) {
-                            V3 so = offset_origin(si.p, si.n, es.d);
-                            V3 sv = es.q - so;
-                            float sd = sqrtf(dot(sv, sv));
-                            V3 sdir = sv * (1.0f / sd);
-                            did_shadow = true;
-                            Hit hs;
-#ifdef PBRT_ABLATE_SHADOW
-                            if (sd > 0.0f) {
-#else
-                            if (!scene_intersect<ACCEL, true, true>(a.sc, ls, so, sdir, sd * (1.0f - K_SHADOW_EPS), &hs)) {
-#endif
-                                float mis = es.delta ? 1.0f : mis_weight(es.pdf, bpdf);
-                                L = {fma_(thr.x * f.x, es.weight.x * mis, L.x), fma_(thr.y * f.y, es.weight.y * mis, L.y),
-                                     fma_(thr.z * f.z, es.weight.z * mis, L.z)};
-                            }
-                        }
-                    }
-                }
-                // ---- BSDF sampling, continuation ray, Russian roulette
-                F4 ub = rng4(ka, kb, 2 + 2 * depth, a.seed);
-                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
-                if (bs.valid) {
-                    thr = thr * bs.weight;
-                    eta *= bs.eta;
-                    V3 nd = to_world(fr, bs.wo);
-                    if (M.type == PBRT_MAT_ULTRA) nd = normalize(nd);
-                    o = offset_origin(si.p, si.n, nd);
-                    d = nd;
-                    prev_pdf = bs.delta ? -1.0f : bs.pdf;
-                    float tm = max3(thr);
-                    survive = true;
-                    if (depth + 1 >= a.rr_depth) {
-                        float q = fminf(tm * eta * eta, 0.95f);
-                        float rq = 1.0f / q;
-                        thr = thr * rq;
-                        if (!(ub.w < q)) survive = false;
-                    }
-                    if (tm == 0.0f) survive = false;
-                }
-            }
-        }
-        if (!survive) {
-            // one 16-byte record per finished path: three 4-byte row stores at a scattered `home` cost three
-            // 32-byte HBM sectors (measured: k_bounce WRITE_SIZE 1.23 x algorithmic), one dwordx4 store costs one
-            typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-            const u32x4 rec = {__float_as_uint(L.x), __float_as_uint(L.y), __float_as_uint(L.z), 0u};
-            __builtin_amdgcn_raw_buffer_store_b128(rec, r_L, home * 16u, 0, 0);
-        }
+        survive = bounce_step<ACCEL>(a, tb, ls, r_L, depth, ka, kb, home, tmax, o, d, thr, L, eta, prev_pdf, did_seg, did_shadow);
     }
     live = survive;
     nseg_w += (uint32_t)__popcll(__ballot(did_seg));
@@ -595,6 +607,181 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? 4 : seg_waves_per_eu(A
         row[stride] += nh_acc;
         row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
         if (NB > 1) row[(2 + min(a.depth + 1, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += mid_acc;
+    }
+}
+
+// ---- k_walk: ONE launch walks every remaining bounce (brute-force kernels) -----------------------------------------------
+// Compaction is local to the segment, so nothing forces a grid-wide barrier between bounces: the workgroup that owns a
+// segment carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers (release
+// fence + workgroup barrier between bounces).  What it saves over one launch per bounce: the drain and ramp of every
+// launch, the launches of the late depths in which most workgroups only find an empty segment, and most of the state
+// READS -- the survivors a workgroup wrote a few microseconds ago are still in its XCD's L2.  Waves whose slots lie
+// beyond the live prefix can never get work again (the prefix only shrinks) and leave for good.  The first trip of the
+// loop may walk NB0 = 2 bounces in registers like k_bounce<.., 2>.  Same arithmetic, same keys: the film does not change.
+#ifndef WALK_WAVES_PER_EU
+#define WALK_WAVES_PER_EU 4
+#endif
+template <bool FIRST, int ACCEL, int NB0>
+__global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const RadArgs a) {
+    static_assert(ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "k_walk: brute-force kernels only");
+    constexpr uint32_t SEG = SEG_BRUTE, W = SEG / 64;
+    __shared__ uint32_t wave_tot[2][W], wave_seg[2][W], wave_shd[2][W], wave_mid[2][W];  // double-buffered over the bounces
+    __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
+    const uint32_t seg = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, base = seg * SEG;
+    uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, SEG) : 0u) : a.seg_in[seg];
+    if (cnt_in == 0) {  // uniform across the workgroup
+        if (tid == 0) a.seg_out[seg] = 0;
+        return;
+    }
+    const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u;
+    // a wave that leaves has published zero counts in both buffers first; s_barrier does not wait for terminated waves,
+    // and it does wait for a wave that has neither arrived nor terminated, so the zeros are in place before anybody scans
+    auto leave_if_idle = [&](uint32_t cnt) {
+        if ((tid & 63u) == 0 && wave_first >= cnt) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wave_tot[b][wid] = 0;
+                wave_seg[b][wid] = 0;
+                wave_shd[b][wid] = 0;
+                wave_mid[b][wid] = 0;
+            }
+        }
+        asm volatile("s_cmp_lt_u32 %0, %1\n\t"
+                     "s_cbranch_scc1 .Lstay_%=\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_endpgm\n"
+                     ".Lstay_%=:" ::"s"(wave_first), "s"(cnt) : "scc", "memory");
+    };
+    leave_if_idle(cnt_in);
+    const uint32_t live_threads = (min(cnt_in, SEG) + 63u) & ~63u;  // waves present at the first trip
+    const LdsScene ls = {nullptr, nullptr, nullptr};
+    const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
+    if (ACCEL == ACCEL_K_BRUTE && FIRST) fill_tables_lds(a.sc, tab_lds, live_threads);
+    const uint32_t cap = a.cap;
+    Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
+    const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
+    uint32_t depth = a.depth, trip = 0, left = 0;
+    uint32_t ns_acc = 0, nh_acc = 0;
+    for (;;) {
+        const uint32_t buf = trip & 1u;
+        const bool first = FIRST && trip == 0;
+        const bool alive = tid < cnt_in;
+        const uint32_t slot = base + tid;
+        bool survive = false, did_seg = false, did_shadow = false;
+        V3 o = {0, 0, 0}, d = {0, 0, 1}, thr = {1, 1, 1}, L = {0, 0, 0};
+        float eta = 1.0f, prev_pdf = -1.0f, tmax = K_INF;
+        uint32_t home = slot, ka = 0, kb = 0, px = 0, py = 0;
+        if (alive) {
+            if (first) {
+                path_key<false>(a, home, &ka, &kb, &px, &py);
+                F4 uj = rng4(ka, kb, 0, a.seed);
+                float fx = (float)px + uj.x, fy = (float)py + uj.y;
+                camera_ray(a.cam, fx / (float)a.film_w, fy / (float)a.film_h, &o, &d, &tmax);
+            } else {
+                const uint32_t v4 = state_voff(slot);
+                constexpr uint32_t row = STATE_ROW_BYTES;
+                o = {bld(r_in, v4 + 0 * row, 0), bld(r_in, v4 + 1 * row, 0), bld(r_in, v4 + 2 * row, 0)};
+                d = {bld(r_in, v4 + 3 * row, 0), bld(r_in, v4 + 4 * row, 0), bld(r_in, v4 + 5 * row, 0)};
+                thr = {bld(r_in, v4 + 6 * row, 0), bld(r_in, v4 + 7 * row, 0), bld(r_in, v4 + 8 * row, 0)};
+                L = {bld(r_in, v4 + 9 * row, 0), bld(r_in, v4 + 10 * row, 0), bld(r_in, v4 + 11 * row, 0)};
+                eta = bld(r_in, v4 + 12 * row, 0);
+                prev_pdf = bld(r_in, v4 + 13 * row, 0);
+                home = __float_as_uint(bld(r_in, v4 + 14 * row, 0));
+            }
+        }
+        // shading tables -> LDS, behind the state loads of the first trip so that the two memory round trips overlap
+        if (ACCEL == ACCEL_K_BRUTE && !FIRST && trip == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
+        if (alive && !first) path_key<false>(a, home, &ka, &kb, &px, &py);
+        const uint32_t nb = (trip == 0) ? (uint32_t)NB0 : 1u;
+        bool live = alive;
+        uint32_t nseg_w = 0, nshd_w = 0, nmid_w = 0;
+#pragma unroll 1
+        for (uint32_t bounce = 0; bounce < nb; ++bounce) {
+            const uint32_t dd = depth + bounce;
+            if (bounce > 0) {
+                if (dd >= a.max_depth) break;  // uniform
+                nmid_w += (uint32_t)__popcll(__ballot(live));
+                tmax = K_INF;
+            }
+            did_seg = false;
+            did_shadow = false;
+            survive = false;
+            if (live) survive = bounce_step<ACCEL>(a, tb, ls, r_L, dd, ka, kb, home, tmax, o, d, thr, L, eta, prev_pdf, did_seg, did_shadow);
+            live = survive;
+            nseg_w += (uint32_t)__popcll(__ballot(did_seg));
+            nshd_w += (uint32_t)__popcll(__ballot(did_shadow));
+        }
+        // ---- segment-local stream compaction (as in k_bounce)
+        const unsigned long long bal = __ballot(survive);
+        const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if ((tid & 63u) == 0) {
+            wave_tot[buf][wid] = (uint32_t)__popcll(bal);
+            wave_seg[buf][wid] = nseg_w;
+            wave_shd[buf][wid] = nshd_w;
+            wave_mid[buf][wid] = nmid_w;
+        }
+        __syncthreads();
+        uint32_t off = 0, total = 0;
+        {
+            const uint32_t t_lane = wave_tot[buf][tid & (W - 1)];
+            const uint32_t wid_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wid);
+#pragma unroll
+            for (uint32_t w = 0; w < W; ++w) {
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)t_lane, (int)w);
+                off += (w < wid_s) ? t : 0u;
+                total += t;
+            }
+        }
+        if (survive) {
+            const uint32_t v4 = state_voff(base + off + prefix);
+            constexpr uint32_t row = STATE_ROW_BYTES;
+            bst(r_out, v4 + 0 * row, 0, o.x);
+            bst(r_out, v4 + 1 * row, 0, o.y);
+            bst(r_out, v4 + 2 * row, 0, o.z);
+            bst(r_out, v4 + 3 * row, 0, d.x);
+            bst(r_out, v4 + 4 * row, 0, d.y);
+            bst(r_out, v4 + 5 * row, 0, d.z);
+            bst(r_out, v4 + 6 * row, 0, thr.x);
+            bst(r_out, v4 + 7 * row, 0, thr.y);
+            bst(r_out, v4 + 8 * row, 0, thr.z);
+            bst(r_out, v4 + 9 * row, 0, L.x);
+            bst(r_out, v4 + 10 * row, 0, L.y);
+            bst(r_out, v4 + 11 * row, 0, L.z);
+            bst(r_out, v4 + 12 * row, 0, eta);
+            bst(r_out, v4 + 13 * row, 0, prev_pdf);
+            bst(r_out, v4 + 14 * row, 0, __uint_as_float(home));
+        }
+        if (tid == 0) {  // wave 0 stays as long as the segment has a live path
+            uint32_t mid = 0;
+            for (uint32_t w = 0; w < W; ++w) {
+                ns_acc += wave_seg[buf][w];
+                nh_acc += wave_shd[buf][w];
+                mid += wave_mid[buf][w];
+            }
+            unsigned long long *row = a.stats + seg;
+            const size_t stride = a.stat_stride;
+            row[(2 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
+            if (nb > 1 && depth + 1 < a.max_depth) row[(2 + min(depth + 1, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += mid;
+        }
+        left = total;
+        depth += nb;
+        if (total == 0 || depth >= a.max_depth) break;  // uniform: `total` is the same in every wave
+        // the survivors just written are the next bounce's input: stores complete (release at workgroup scope; the waves
+        // of a workgroup share the CU's vector L1), and everybody has finished reading the old input
+        __threadfence_block();
+        __syncthreads();
+        const Rsrc t_r = r_in;
+        r_in = r_out;
+        r_out = t_r;
+        cnt_in = total;
+        ++trip;
+        leave_if_idle(cnt_in);
+    }
+    if (tid == 0) {
+        a.seg_out[seg] = left;
+        unsigned long long *row = a.stats + seg;
+        row[0] += ns_acc;
+        row[a.stat_stride] += nh_acc;
     }
 }
 

@@ -392,6 +392,26 @@ int pbrt_scene_destroy(pbrt_scene *s) {
 #ifndef PBRT_DEFAULT_FUSE_PLAN
 #define PBRT_DEFAULT_FUSE_PLAN 0x1u
 #endif
+// Depth from which one launch walks every remaining bounce of a pass (k_walk; 0xff: never).  PBRT_FILM_WALK_FROM overrides.
+#ifndef PBRT_DEFAULT_WALK_FROM
+#define PBRT_DEFAULT_WALK_FROM 0xffu
+#endif
+
+template <bool FIRST>
+static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb0) {
+    hipStream_t st = s->ctx->stream;
+    if (s->accel_kernel == ACCEL_K_BRUTE) {
+        if (nb0 == 2)
+            hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE, 1>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+    } else {
+        if (nb0 == 2)
+            hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE_BIG, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+        else
+            hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE_BIG, 1>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+    }
+}
 // nb: bounces this launch walks (2: the fused variants of the brute-force kernels, kernels_radiance.h)
 template <bool FIRST>
 static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
@@ -546,6 +566,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         uint32_t *sin = segA, *sout = segB;
         const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
         const uint32_t fuse_plan = (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN;
+        const uint32_t walk_from = (f->flags & PBRT_FILM_WALK_SET) ? ((f->flags >> 17) & 0xffu) : PBRT_DEFAULT_WALK_FROM;
         for (uint32_t depth = 0; depth < f->max_depth;) {
             // bounces this launch walks: 2 at the depths of the fuse plan (brute-force kernels; the last bounce of a
             // path only looks for emitters, so it is never worth a launch slot of its own either)
@@ -575,12 +596,20 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 n_ev += 2;
                 HIPCHK(c, hipEventRecord(e0, st));
             }
-            if (depth == 0)
+            const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
+            if (walk) {
+                if (depth == 0)
+                    launch_walk<true>(s, a, nseg_pass, nb);
+                else
+                    launch_walk<false>(s, a, nseg_pass, nb);
+            } else if (depth == 0) {
                 launch_bounce<true>(s, a, nseg_pass, nb);
-            else
+            } else {
                 launch_bounce<false>(s, a, nseg_pass, nb);
+            }
             HIPCHK(c, hipGetLastError());
             ++launches;
+            if (walk) break;
             std::swap(in, out);
             std::swap(sin, sout);
             const uint32_t depth_before = depth;

@@ -322,5 +322,11 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
         assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
         assert st["bounce_launches"] <= st0["bounce_launches"] and st["bounce_model_bytes"] <= st0["bounce_model_bytes"]
     assert np.array_equal(integ.render(sc, seed=5, spp=6), base)          # the library's default plan
+    # k_walk: one launch walks every remaining bounce of a pass (PBRT_FILM_WALK_FROM), with and without a fused first trip
+    for plan, walk in ((0x0, 0), (0x1, 0), (0x0, 1), (0x1, 2), (0x4, 2), (0x0, 3)):
+        img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(plan) | capi.film_walk_from(walk))
+        st = ctx.stats()
+        assert np.array_equal(img, base), (hex(plan), walk)
+        assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
     # passes: a short last pass and the fused first launch
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)

@@ -1,0 +1,25 @@
+"""A/B of the launch structure of the brute-force radiance kernels on cbox 512^2 x 256 spp: fuse plan (two bounces per launch
+in registers) x walk depth (one launch for all remaining bounces).  Film must not change.  usage: python tools/walk_ab.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import pbrt_amd as mi
+capi = __import__("importlib").import_module("physics-based-ray-tracing_amd._capi")
+sc = mi.load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/scenes/cbox.xml"), res=512, spp=256)
+integ = sc.integrator()
+ctx = mi.default_context()
+ref = None
+cases = [(0x0, 0xff), (0x1, 0xff), (0x1, 2), (0x1, 0), (0x0, 0), (0x0, 1), (0x0, 2), (0x1, 3), (0x5, 2)]
+if len(sys.argv) > 1:
+    cases = [tuple(int(x, 16) for x in a.split(":")) for a in sys.argv[1:]]
+for plan, walk in cases:
+    best = None
+    for _ in range(6):
+        img = integ.render(sc, seed=0, spp=256, flags=capi.film_fuse_plan(plan) | capi.film_walk_from(walk))
+        st = ctx.stats()
+        if best is None or st["kernel_ms"] < best["kernel_ms"]:
+            best = st
+    if ref is None:
+        ref = img
+    print(f"fuse {plan:#04x} walk_from {walk:#04x}: kernel {best['kernel_ms']:.3f} ms  bounce {best['bounce_ms']:.3f} ms  launches {best['bounce_launches']}  "
+          f"live {list(best['live'][:6])} seg {best['segments']}  same film {bool(np.array_equal(img, ref))}  -> {512*512*256/best['kernel_ms']/1e3:.0f} Msamples/s", flush=True)

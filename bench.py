@@ -175,9 +175,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    keep = {}
+
     def step():
         if radiance:
-            tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account)
+            tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
+                                            tile=keep.get("tile"))
+            keep["tile"] = tile
             if args.rehearse_on_one_gpu and world > 1:
                 tile = tile.cpu()  # gloo gathers host tensors
             return par.gather_film(tile, layout, RES, RES, rank, world)

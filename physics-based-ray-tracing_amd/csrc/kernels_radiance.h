@@ -785,20 +785,24 @@ __global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const Rad
     }
 }
 
-// column sums of the per-segment statistics: out[k] = sum_seg stats[k][seg]
+// column sums of the per-segment statistics: out[k] += sum_seg stats[k][seg].  grid (rows, REDUCE_SLICES): every block sums
+// one slice of a row and adds it to the row's total with one 64-bit atomic (out is zeroed by the caller; a single block
+// per row took 55 us for the 32 Ki rows of a 16 Mi-path pass, on the host's critical path of every call)
+#define REDUCE_SLICES 32
 __global__ __launch_bounds__(256) void k_reduce_stats(const unsigned long long *stats, uint32_t nseg, size_t stride,
                                                       unsigned long long *out) {
     __shared__ unsigned long long part[256];
     const unsigned long long *row = stats + (size_t)blockIdx.x * stride;
+    const uint32_t per = (nseg + gridDim.y - 1) / gridDim.y, lo = min(blockIdx.y * per, nseg), hi = min(lo + per, nseg);
     unsigned long long s = 0;
-    for (uint32_t i = threadIdx.x; i < nseg; i += 256) s += row[i];
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) s += row[i];
     part[threadIdx.x] = s;
     __syncthreads();
     for (uint32_t w = 128; w > 0; w >>= 1) {
         if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+    if (threadIdx.x == 0 && part[0]) atomicAdd(&out[blockIdx.x], part[0]);
 }
 
 // ---- film: deterministic gather of the pass's samples through the reconstruction filter -----------

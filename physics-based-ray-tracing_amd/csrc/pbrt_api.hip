@@ -516,8 +516,10 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
     const uint32_t n_rows = nseg * rad_rows_per_region(s->accel_kernel);         // statistics rows
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_rows * 8;  // reduced at the end
-    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
+    // statistics rows in use: segments, shadow rays, one per depth (cleared and reduced per call: keep it to what the call touches)
+    const uint32_t stat_rows = 2 + (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS);
+    const size_t segstats_bytes = (size_t)stat_rows * n_rows * 8;  // reduced at the end
+    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", (size_t)(2 + MAX_DEPTH_STATS) * n_rows * 8);
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
     if (repack && (!stC || !segC || !offs || !quota)) return PBRT_E_NOMEM;
@@ -668,7 +670,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_rows, (size_t)n_rows, dstats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(stat_rows, REDUCE_SLICES), dim3(256), 0, st, segstats, n_rows, (size_t)n_rows, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -994,7 +996,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
     unsigned long long hstats[2 + MAX_DEPTH_STATS];
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
+    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));

@@ -42,11 +42,12 @@ def _dist():
 
 
 def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=None, device=None, sample_offset=0,
-                 on_call=None):
+                 on_call=None, tile=None):
     """Render this rank's bands into one [rows_max, W, 3] float32 torch tensor (padded to the largest
     rank).  render_band(crop, out_rows_tensor) fills a [rows, W, 3] view; the default calls the HIP
     library and writes straight into the tensor's device memory (no PCIe traffic).  on_call() runs after
-    every library call (one per band; bench.py adds up the per-call statistics there)."""
+    every library call (one per band; bench.py adds up the per-call statistics there).  tile: a tensor of a previous call
+    to render into again (every row of a rank's bands is overwritten)."""
     import torch
 
     sens = scene.sensors()[0]
@@ -54,7 +55,8 @@ def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=N
     layout = band_layout(H, world_size, band_rows)
     rows_max = max(rows_of(l) for l in layout)
     dev = device if device is not None else torch.device("cpu")
-    tile = torch.zeros((rows_max, W, 3), dtype=torch.float32, device=dev)
+    if tile is None or tuple(tile.shape) != (rows_max, W, 3) or tile.device != dev:
+        tile = torch.zeros((rows_max, W, 3), dtype=torch.float32, device=dev)
     integ = scene.integrator()
     off = 0
     for (y0, rows) in layout[rank]:

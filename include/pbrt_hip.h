@@ -119,6 +119,11 @@ typedef struct pbrt_scene_desc {
     const uint32_t *light_prims;
     const float *light_cdf;
     uint32_t accel; /* PBRT_ACCEL_* */
+    /* optional, [n_prims][9]: the vertex normals n0, n1, n2 (world space, unit length) of a primitive of a mesh that has
+     * them: the shading normal of a hit is si.sh_frame.n = normalize(b0 n0 + b1 n1 + b2 n2) (Mitsuba Mesh), the geometric
+     * normal g[9..11] stays the one rays are offset along.  A PARALLELOGRAM row holds one normal three times (a merged
+     * quad keeps its vertex normals only if they all agree).  All-zero row, or NULL: the face normal. */
+    const float *vertex_normals;
 } pbrt_scene_desc;
 
 /* ---- camera / film (radiance mode) -------------------------------------------------------- */

@@ -63,9 +63,9 @@ f32 = _capi.f32
 class OracleScene:
     """CPU oracle twin of _capi.DeviceScene (same pbrt_scene_desc arrays)."""
 
-    def __init__(self, prims, materials, emitters, light_prims, light_cdf, accel=_capi.ACCEL_AUTO):
-        self._keep = (prims, materials, emitters, light_prims, light_cdf)
-        desc = _capi.fill_scene_desc(prims, materials, emitters, light_prims, light_cdf, accel)
+    def __init__(self, prims, materials, emitters, light_prims, light_cdf, accel=_capi.ACCEL_AUTO, vertex_normals=None):
+        self._keep = (prims, materials, emitters, light_prims, light_cdf, vertex_normals)
+        desc = _capi.fill_scene_desc(prims, materials, emitters, light_prims, light_cdf, accel, vertex_normals)
         h = _P()
         _chk(lib().oracle_scene_create(C.byref(desc), C.byref(h)), "oracle_scene_create")
         self.handle = h
@@ -74,7 +74,7 @@ class OracleScene:
     def from_scene(cls, scene, accel=None):
         f = scene.flatten()
         return cls(f["prims"], f["materials"], f["emitters"], f["light_prims"], f["light_cdf"],
-                   scene.accel if accel is None else accel)
+                   scene.accel if accel is None else accel, f.get("vertex_normals"))
 
     def update_material(self, index, m):
         _chk(lib().oracle_scene_update_material(self.handle, C.c_uint32(index), C.byref(m)), "oracle_scene_update_material")

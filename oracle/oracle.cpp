@@ -45,6 +45,7 @@ struct Scene {
     std::vector<pbrt_emitter> emitters;
     std::vector<uint32_t> light_prims;
     std::vector<float> light_cdf;
+    std::vector<float> vnormals;  // optional [n_prims][9] vertex normals (pbrt_scene_desc.vertex_normals), caller order
     bool use_bvh = false;
     std::vector<pbrt_prim> occ;  // brute-force scenes: primitives that can occlude a segment (find_occluders)
     std::vector<BvhNode> nodes;
@@ -476,7 +477,8 @@ void build_bvh(Scene &sc) {
 // Surface interaction
 // ------------------------------------------------------------------------------------------------
 struct SI {
-    V3 p, n;  // hit point, geometric == shading normal (face normals)
+    V3 p, n;  // hit point, geometric normal (rays are offset along it)
+    V3 ns;    // shading normal si.sh_frame.n: interpolated vertex normals where the mesh has them, else n
     const pbrt_prim *prim;
 };
 
@@ -502,6 +504,20 @@ inline SI make_si(const Scene &sc, V3 o, V3 d, const Hit &h) {
     } else {
         si.p = madd(g3(P, 6), h.v, madd(g3(P, 3), h.u, g3(P, 0)));
         si.n = g3(P, 9);
+    }
+    // Mitsuba Mesh::compute_surface_interaction: sh_frame.n = normalize(b0 n0 + b1 n1 + b2 n2)
+    si.ns = si.n;
+    if (!sc.vnormals.empty() && (P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM)) {
+        const float *r = &sc.vnormals[(size_t)h.prim * 9];
+        const V3 n0 = {r[0], r[1], r[2]}, n1 = {r[3], r[4], r[5]}, n2 = {r[6], r[7], r[8]};
+        if (dot(n0, n0) + dot(n1, n1) + dot(n2, n2) > 0.0f) {
+            if (P.type == PBRT_PRIM_PARALLELOGRAM) {
+                si.ns = normalize(n0);
+            } else {
+                const float b0 = 1.0f - h.u - h.v;
+                si.ns = normalize(madd(n0, b0, madd(n1, h.u, n2 * h.v)));
+            }
+        }
     }
     return si;
 }
@@ -835,7 +851,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
         // ---- direct emission (area emitters are one-sided)
         if (P.emitter >= 0) {
             const pbrt_emitter &E = sc.emitters[P.emitter];
-            float cosl = -dot(si.n, d);
+            float cosl = -dot(si.ns, d);  // Frame::cos_theta(si.wi): the shading frame (== n on emitters)
             if (cosl > 0.0f) {
                 float w = 1.0f;
                 if (!prev_delta) {
@@ -848,7 +864,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
         }
         if (depth + 1 >= max_depth) break;
         const pbrt_material &M = sc.mats[P.material];
-        Frame fr = make_frame(si.n);
+        Frame fr = make_frame(si.ns);
         V3 wi = to_local(fr, -d);
         // ---- emitter sampling
         if (mat_smooth(M) && nE > 0) {
@@ -876,7 +892,7 @@ V3 path_radiance(const Scene &sc, V3 o, V3 d, float tmax, uint32_t ka, uint32_t 
         }
         // ---- BSDF sampling
         F4 ub = rng4(ka, kb, 2 + 2 * depth, seed);
-        BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
+        BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.ns, fr, ub.x, ub.y, ub.z);
         if (!bs.valid) break;
         thr = thr * bs.weight;
         eta *= bs.eta;
@@ -938,6 +954,7 @@ int oracle_scene_create(const pbrt_scene_desc *desc, oracle_scene **out) {
     s->sc.emitters.assign(desc->emitters, desc->emitters + desc->n_emitters);
     s->sc.light_prims.assign(desc->light_prims, desc->light_prims + desc->n_light_prims);
     s->sc.light_cdf.assign(desc->light_cdf, desc->light_cdf + desc->n_light_prims);
+    if (desc->vertex_normals) s->sc.vnormals.assign(desc->vertex_normals, desc->vertex_normals + (size_t)desc->n_prims * 9);
     for (auto &p : s->sc.prims) {
         double cc[3], ca[3], cb[3], cx[3];
         if (p.type > PBRT_PRIM_CONE || p.material >= desc->n_materials ||
@@ -1160,7 +1177,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     float phase = two_pi_f * total_time;                                       // :330
                     const pbrt_material &M = sc.mats[si.prim->material];
                     // si.sh_frame as Mitsuba builds it: from the shape's dp_du (initialize_sh_frame), not coordinate_system(n)
-                    const Frame fr = make_sh_frame(si.n, si_dp_du(si));
+                    const Frame fr = make_sh_frame(si.ns, si_dp_du(si));
                     V3 wi = to_local(fr, -d);                                                  // si.wi (CustomBSDF.py:90)
                     float a_resp, bpdf;
                     V3 new_dir;
@@ -1168,21 +1185,21 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                         // intent arithmetic (A2 off): the micro-normal's second variate comes from a second block of the
                         // path's stream; u.w decides the roulette (:365) and must not steer the facet as well
                         const float s1b = (p->quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, seed).x;
-                        UltraOut uo = ultra_core(M, p->quirks, wi, si.n, si.n, u.y, u.z, s1b); // :338
+                        UltraOut uo = ultra_core(M, p->quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
                         a_resp = uo.amp;
                         bpdf = uo.pdf;
                         // :165 + :358: to_world(to_local(chosen))
                         new_dir = to_world(fr, to_local(fr, uo.chosen));
                     } else {
-                        BSample bs = bsdf_sample(M, p->quirks, wi, si.n, si.n, fr, u.y, u.z, u.w);
+                        BSample bs = bsdf_sample(M, p->quirks, wi, si.n, si.ns, fr, u.y, u.z, u.w);
                         if (!bs.valid) break;
                         a_resp = bs.weight.x;
                         bpdf = bs.pdf;
                         new_dir = to_world(fr, bs.wo);
                     }
-                    float cos_theta = dot(si.n, -d);                                           // :340
+                    float cos_theta = dot(si.ns, -d);                                          // :340 (si.sh_frame.n)
                     amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                            // :341
-                    float w_o = dot(d, si.n) / num_rays;                                       // :286-287,345
+                    float w_o = dot(d, si.ns) / num_rays;                                      // :286-287,345 (si.sh_frame.n)
                     float fd = directivity_weight_i(sec_dir, tn, am, ac) * w_o;                // :345
                     float pressure = atten * amp * fd * ((p->quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase));  // :348 / f-3
                     float tf = rintf(total_time * p->fs);                                      // :351-352 (half-to-even)

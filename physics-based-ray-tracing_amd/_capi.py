@@ -75,7 +75,7 @@ class SceneDesc(C.Structure):
                 ("n_materials", C.c_uint32), ("materials", C.c_void_p),
                 ("n_emitters", C.c_uint32), ("emitters", C.c_void_p),
                 ("n_light_prims", C.c_uint32), ("light_prims", C.c_void_p), ("light_cdf", C.c_void_p),
-                ("accel", C.c_uint32)]
+                ("accel", C.c_uint32), ("vertex_normals", C.c_void_p)]
 
 
 class Camera(C.Structure):
@@ -299,7 +299,7 @@ def default_context(device: int | None = None) -> Context:
 
 
 def fill_scene_desc(prims: np.ndarray, materials: np.ndarray, emitters: np.ndarray, light_prims: np.ndarray,
-                    light_cdf: np.ndarray, accel: int = ACCEL_AUTO) -> SceneDesc:
+                    light_cdf: np.ndarray, accel: int = ACCEL_AUTO, vertex_normals: np.ndarray | None = None) -> SceneDesc:
     """The arrays must stay alive while the returned descriptor is in use."""
     assert prims.dtype == PRIM_DTYPE and materials.dtype == MATERIAL_DTYPE and emitters.dtype == EMITTER_DTYPE
     d = SceneDesc()
@@ -313,16 +313,21 @@ def fill_scene_desc(prims: np.ndarray, materials: np.ndarray, emitters: np.ndarr
     d.light_prims = addr(light_prims) if len(light_prims) else None
     d.light_cdf = addr(light_cdf) if len(light_cdf) else None
     d.accel = accel
+    if vertex_normals is not None:
+        assert vertex_normals.dtype == np.float32 and vertex_normals.shape == (len(prims), 9) and vertex_normals.flags["C_CONTIGUOUS"]
+        d.vertex_normals = addr(vertex_normals)
+    else:
+        d.vertex_normals = None
     return d
 
 
 class DeviceScene:
     """pbrt_scene handle: device-resident primitives / materials / emitters (+ BVH)."""
 
-    def __init__(self, ctx: Context, prims, materials, emitters, light_prims, light_cdf, accel=ACCEL_AUTO):
+    def __init__(self, ctx: Context, prims, materials, emitters, light_prims, light_cdf, accel=ACCEL_AUTO, vertex_normals=None):
         self.ctx = ctx
-        self._keep = (prims, materials, emitters, light_prims, light_cdf)
-        desc = fill_scene_desc(prims, materials, emitters, light_prims, light_cdf, accel)
+        self._keep = (prims, materials, emitters, light_prims, light_cdf, vertex_normals)
+        desc = fill_scene_desc(prims, materials, emitters, light_prims, light_cdf, accel, vertex_normals)
         h = _P()
         ctx.check(ctx.lib.pbrt_scene_create(ctx.handle, C.byref(desc), C.byref(h)), "pbrt_scene_create")
         self.handle = h

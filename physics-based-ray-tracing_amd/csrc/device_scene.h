@@ -42,6 +42,8 @@ struct DevScene {
     const struct PairItem *pair_items;  // ACCEL_K_BRUTE: sc.prims as pairs of planar primitives (brute_closest_pairs)
     uint32_t n_pair_items;
 #endif
+    // optional: the vertex normals of mesh primitives, [n_prims][9], indexed like `prims` (by Hit::slot); nullptr: face normals
+    const float *vnormals;
     uint32_t n_prims, n_nodes, n_emitters, n_mats, n_light_prims;
 };
 
@@ -511,10 +513,24 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
 
 // ---- surface interaction ------------------------------------------------------------------------
 struct SI {
-    V3 p, n;
+    V3 p, n;  // hit point, geometric normal (rays are offset along it)
+    V3 ns;    // shading normal si.sh_frame.n: interpolated vertex normals where the mesh has them, else n
 };
+// Mitsuba Mesh::compute_surface_interaction: sh_frame.n = normalize(b0 n0 + b1 n1 + b2 n2) with the barycentrics of the hit.
+// SHN: compiled into the BVH and the _BIG brute-force kernels only (a small scene with vertex normals takes the _BIG
+// variant, like one with a cone: the 64-VGPR Cornell-box kernel has no registers to spare).
+template <bool SHN>
+DEV V3 shading_normal(const pbrt_prim &P, V3 n, float u, float v, const float *vn, uint32_t slot) {
+    if (!SHN || vn == nullptr || (P.type != PBRT_PRIM_TRIANGLE && P.type != PBRT_PRIM_PARALLELOGRAM)) return n;
+    const float *r = vn + 9u * slot;
+    const V3 n0 = {r[0], r[1], r[2]}, n1 = {r[3], r[4], r[5]}, n2 = {r[6], r[7], r[8]};
+    if (!(dot(n0, n0) + dot(n1, n1) + dot(n2, n2) > 0.0f)) return n;  // no vertex normals on this primitive
+    if (P.type == PBRT_PRIM_PARALLELOGRAM) return normalize(n0);      // a merged quad: all its vertex normals agree
+    const float b0 = 1.0f - u - v;
+    return normalize(madd(n0, b0, madd(n1, u, n2 * v)));
+}
 template <bool CONES = true>
-DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
+DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v, const float *vn = nullptr, uint32_t slot = 0) {
     SI si;
     if (P.type == PBRT_PRIM_SPHERE) {
         V3 c = g3(P, 0);
@@ -537,6 +553,7 @@ DEV SI make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v) {
         si.p = madd(g3(P, 6), v, madd(g3(P, 3), u, g3(P, 0)));
         si.n = g3(P, 9);
     }
+    si.ns = shading_normal<CONES>(P, si.n, u, v, vn, slot);
     return si;
 }
 

@@ -268,13 +268,13 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
         if (scene_intersect<ACCEL, false>(a.sc, ls, o, d, tmax, &h)) {
             did_seg = true;
             const pbrt_prim &P = tb.prims_by_slot[h.slot];
-            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
+            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v, a.sc.vnormals, h.slot);
             const int32_t emitter = P.emitter;
             const uint32_t mat_id = P.material;
             // ---- direct emission (one-sided area emitters), MIS against emitter sampling
             if (emitter >= 0) {
                 const pbrt_emitter &E = tb.emitters[emitter];
-                float cosl = -dot(si.n, d);
+                float cosl = -dot(si.ns, d);  // Frame::cos_theta(si.wi): the shading frame (== n on emitters)
                 if (cosl > 0.0f) {
                     float w = 1.0f;
                     if (prev_pdf >= 0.0f) {
@@ -287,7 +287,7 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
             }
             if (depth + 1 < a.max_depth) {
                 const pbrt_material M = tb.mats[mat_id];
-                Frame fr = make_frame(si.n);
+                Frame fr = make_frame(si.ns);
                 V3 wi = to_local(fr, -d);
                 // ---- emitter sampling (next-event estimation) + shadow ray
 #ifdef PBRT_ABLATE_NEE  // diagnostic builds only (tools/ablate.sh): never defined in the shipped library
@@ -323,7 +323,7 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
                 }
                 // ---- BSDF sampling, continuation ray, Russian roulette
                 F4 ub = rng4(ka, kb, 2 + 2 * depth, a.seed);
-                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.n, fr, ub.x, ub.y, ub.z);
+                BSample bs = bsdf_sample(M, PBRT_USQ_REFERENCE, wi, si.n, si.ns, fr, ub.x, ub.y, ub.z);
                 if (bs.valid) {
                     thr = thr * bs.weight;
                     eta *= bs.eta;

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         if (hit) {
             did_seg = true;
             const pbrt_prim &P = tb.prims_by_slot[h.slot];
-            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v);
+            SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v, a.sc.vnormals, h.slot);
             const float distance = h.t;                                                // :314
             geo_len += distance;                                                       // :315
             const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             atten *= expf(a.katt * distance / 8.686f);                                 // :328
             const pbrt_material M = tb.mats[P.material];
             // si.sh_frame as Mitsuba builds it (from dp_du, not coordinate_system(n)): si.wi, si.to_local, si.to_world
-            const Frame fr = make_sh_frame(si.n, si_dp_du<ACCEL != ACCEL_K_BRUTE>(P, si));
+            const Frame fr = make_sh_frame(si.ns, si_dp_du<ACCEL != ACCEL_K_BRUTE>(P, si));
             V3 wi = to_local(fr, -d);                                                  // si.wi (CustomBSDF.py:90)
             float a_resp, bpdf;
             V3 new_dir;
@@ -229,19 +229,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                 // intent arithmetic (no diagonal broadcast, A2 off): the micro-normal's second variate comes from a second
                 // block of the path's stream -- u.w also decides the roulette below and must not steer the facet as well
                 const float s1b = (a.p.quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, a.seed).x;
-                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.n, u.y, u.z, s1b); // :338
+                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
                 a_resp = uo.amp;
                 bpdf = uo.pdf;
                 new_dir = to_world(fr, to_local(fr, uo.chosen));                       // CustomBSDF.py:165 + :358
             } else {
-                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.n, fr, u.y, u.z, u.w);
+                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.ns, fr, u.y, u.z, u.w);
                 ok = bs.valid;
                 a_resp = bs.weight.x;
                 bpdf = bs.pdf;
                 new_dir = to_world(fr, bs.wo);
             }
             if (ok) {
-                float cos_theta = dot(si.n, -d);                                       // :340
+                float cos_theta = dot(si.ns, -d);                                      // :340 (si.sh_frame.n)
                 amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                        // :341
                 float fd, carrier;
                 uint32_t ci = 0xffffffffu;
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                     carrier = rx.y;
                     ci = __float_as_uint(rx.z);
                 } else {
-                    float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);             // :286-287,345
+                    float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);            // :286-287,345 (si.sh_frame.n)
                     fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;          // :345
                     // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
                     carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_ray
         const uint32_t T = a.p.time_samples;
         const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
         const pbrt_prim &P = a.sc.prims[h.slot];
-        SI si = make_si(P, o, d, h.t, h.u, h.v);
+        SI si = make_si(P, o, d, h.t, h.u, h.v, a.sc.vnormals, h.slot);
         const float distance = h.t;                                                      // :314
         const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
         float tof = 0.0f;                                                                // :278
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_ray
         float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
         float total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;                 // :329
         float phase = a.two_pi_f * total_time;                                           // :330
-        float w_o = dot(d, si.n) / (float)(a.p.n_angles * NE);                           // :286-287,345
+        float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);                          // :286-287,345 (si.sh_frame.n)
         rx.x = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;                      // :345
         rx.y = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
         float tf = rintf(total_time * a.p.fs);                                           // :351-352

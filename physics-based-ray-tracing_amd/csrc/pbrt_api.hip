@@ -287,6 +287,9 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
             return c->fail(PBRT_E_INVALID, "emitter %u: unknown type", i);
         }
     }
+    if (d->vertex_normals)
+        for (size_t i = 0; i < (size_t)d->n_prims * 9; ++i)
+            if (!std::isfinite(d->vertex_normals[i])) return c->fail(PBRT_E_INVALID, "vertex_normals: entry %zu is not finite", i);
     HIPCHK(c, hipSetDevice(c->device));
     pbrt_scene *s = new pbrt_scene();
     s->ctx = c;
@@ -321,6 +324,8 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
         for (uint32_t i = 0; i < d->n_prims; ++i)
             if (d->prims[i].type == PBRT_PRIM_CONE) small = false;  // only the _BIG variant carries the cone code
+        if (d->vertex_normals) small = false;                      // ... and the shading-normal code
+        if (d->vertex_normals) UP(upload(s, d->vertex_normals, (size_t)d->n_prims * 9, &s->ds.vnormals));
         s->accel_kernel = small ? ACCEL_K_BRUTE : ACCEL_K_BRUTE_BIG;
         std::vector<pbrt_prim> occ = find_occluders(d);
         UP(upload(s, occ.data(), occ.size(), &s->ds.occ_prims));
@@ -344,6 +349,12 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         for (uint32_t k = 0; k < d->n_prims; ++k) ordered[k] = d->prims[bvh.order[k]];
         UP(upload(s, ordered.data(), ordered.size(), &s->ds.prims));
         UP(upload(s, bvh.order.data(), bvh.order.size(), &s->ds.prim_ids));
+        if (d->vertex_normals) {  // in leaf order, like the primitives: make_si indexes them by Hit::slot
+            std::vector<float> vn((size_t)d->n_prims * 9);
+            for (uint32_t k = 0; k < d->n_prims; ++k)
+                std::memcpy(&vn[(size_t)k * 9], d->vertex_normals + (size_t)bvh.order[k] * 9, 36);
+            UP(upload(s, vn.data(), vn.size(), &s->ds.vnormals));
+        }
         std::vector<HostInner> inner;
         to_inner_nodes(bvh, &inner);
         static_assert(sizeof(HostInner) == sizeof(DevNode), "node layout");

@@ -163,11 +163,20 @@ class MeshShape(Shape):
     def __init__(self, props):
         super().__init__(props)
         self.filename = props["filename"]
-        v, t = load_mesh(self.filename)
+        v, t, tn = load_mesh(self.filename, normals=True)
         self.vertices = self.to_world.transform_affine(v)
         self.faces = t
-        # vertex normals are not used: face normals only
+        # Mitsuba meshes: vertex normals, if the file has them and `face_normals` is not set, are interpolated into the
+        # shading normal si.sh_frame.n = normalize(b0 n0 + b1 n1 + b2 n2); they go to world space with the inverse transpose
+        self.face_normals = bool(props.get("face_normals", False))
+        self.tri_normals = None
+        if tn is not None and not self.face_normals:
+            M = np.linalg.inv(self.to_world.matrix[:3, :3]).T
+            w = tn @ M.T
+            ln = np.linalg.norm(w, axis=2, keepdims=True)
+            self.tri_normals = np.where(ln > 0, w / np.where(ln > 0, ln, 1.0), 0.0)        # [nt, 3, 3]
         self.merge_quads = bool(props.get("merge_quads", True))
+        self.shading_normals = None   # [n_prims, 9] float32 after primitives(), or None
 
     def primitives(self):
         """Triangles; a fan pair (a,b,c),(a,c,d) whose f32 corners form an exact parallelogram
@@ -175,8 +184,11 @@ class MeshShape(Shape):
         surface, one intersection test instead of two ("analytic quads", BASELINE config 2)."""
         v = self.vertices
         t = self.faces
+        tn = self.tri_normals
         if self.flip_normals:
             t = t[:, [0, 2, 1]]
+            if tn is not None:
+                tn = -tn[:, [0, 2, 1]]
         vf = v.astype(np.float32)
         merged = np.zeros(len(t), bool)   # second triangle of a merged pair
         quad = np.zeros(len(t), bool)     # first triangle of a merged pair
@@ -184,6 +196,10 @@ class MeshShape(Shape):
             a, b, c = t[:-1, 0], t[:-1, 1], t[:-1, 2]
             a2, c2, d2 = t[1:, 0], t[1:, 1], t[1:, 2]
             cand = (a == a2) & (c == c2) & np.all(vf[a] + vf[c] == vf[b] + vf[d2], axis=1)
+            if tn is not None:   # a quad keeps ONE shading normal: merge only where all its vertex normals agree
+                tf = tn.astype(np.float32)
+                same = np.all(tf[:-1] == tf[:-1, :1], axis=(1, 2)) & np.all(tf[1:] == tf[:-1, :1], axis=(1, 2))
+                cand &= same
             k = 0
             while k < len(cand):      # greedy, non-overlapping pairs
                 if cand[k]:
@@ -193,11 +209,15 @@ class MeshShape(Shape):
                 else:
                     k += 1
         rec = _tri_records(v[t[:, 0]], v[t[:, 1]], v[t[:, 2]], _capi.PRIM_TRIANGLE)
+        sn = tn.reshape(len(t), 9).astype(np.float32) if tn is not None else None
         if quad.any():
             qi = np.nonzero(quad)[0]
             q = _tri_records(v[t[qi, 0]], v[t[qi, 1]], v[t[qi + 1, 2]], _capi.PRIM_PARALLELOGRAM)
             rec[qi] = q
             rec = rec[~merged]
+            if sn is not None:
+                sn = sn[~merged]
+        self.shading_normals = sn
         return rec
 
 
@@ -436,10 +456,14 @@ class Scene(Object):
             return self._flat
         mats, mat_index = [], {}
         emitters = []
-        prim_blocks = []
+        prim_blocks, sn_blocks = [], []
         light_prims, light_cdf = [], []
         for si, sh in enumerate(self._shapes):
             rec = sh.primitives()
+            sn = getattr(sh, "shading_normals", None)
+            if sn is not None and sh.emitter() is not None:
+                sn = None   # area lights shade and are sampled with their face normals (DESIGN D8)
+            sn_blocks.append(sn if sn is not None else np.zeros((len(rec), 9), np.float32))
             b = sh.bsdf()
             if b is None:
                 b = _default_bsdf()
@@ -488,8 +512,9 @@ class Scene(Object):
             t, p = b.to_material()
             marr["type"][i] = t
             marr["p"][i, :len(p)] = p
+        vnormals = np.ascontiguousarray(np.concatenate(sn_blocks), dtype=np.float32) if sn_blocks else np.zeros((0, 9), np.float32)
         self._flat = dict(
-            prims=np.ascontiguousarray(prims), materials=marr,
+            prims=np.ascontiguousarray(prims), materials=marr, vertex_normals=vnormals if np.any(vnormals) else None,
             emitters=np.concatenate(emitters) if emitters else np.zeros(0, dtype=_capi.EMITTER_DTYPE),
             light_prims=np.asarray(light_prims, dtype=np.uint32), light_cdf=np.asarray(light_cdf, dtype=np.float32),
             material_objects=mats)
@@ -501,7 +526,7 @@ class Scene(Object):
             f = self.flatten()
             ctx = _capi.default_context()
             self._dev = _capi.DeviceScene(ctx, f["prims"], f["materials"], f["emitters"], f["light_prims"],
-                                          f["light_cdf"], self.accel)
+                                          f["light_cdf"], self.accel, f["vertex_normals"])
         if self._dirty_materials:
             f = self.flatten()
             for i in sorted(self._dirty_materials):

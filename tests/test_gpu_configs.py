@@ -114,3 +114,17 @@ def test_bench_multi_gpu_rehearsal_launches_itself(tmp_path):
     assert "interleaved 64-row bands" in out["config"]["workload"] and out["config"]["baseline_config"] == 5
     assert out["rehearsal"]["stitched_equals_unsharded"] is True
     assert out["config"]["samples_per_step"] == 4096 * 4096 * 4 and out["value"] > 0
+
+
+def test_bench_rehearsal_of_the_ultrasound_split(tmp_path):
+    """`bench.py --config us_sphere_box --gpus 2 --rehearse-on-one-gpu`: contiguous path ranges per rank, one reduce(sum); the
+    reduced channel buffer equals the unsharded acquisition (f32 sums in another order)"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "us_sphere_box", "--gpus", "2", "--rehearse-on-one-gpu",
+                        "--steps", "1", "--warmup", "0", "--spp", "4096"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 3 and "one reduce(sum)" in out["config"]["workload"]
+    assert out["rehearsal"]["rel_l2_vs_unsharded"] <= 1e-5 and out["config"]["samples_per_step"] == 5 * 64 * 4096

@@ -137,3 +137,41 @@ def test_occluder_pruning_changes_nothing_on_the_device(mi, ob, capi, bulb):
     cb = mi.load_file(scene_path("cbox.xml"), res=64, spp=8)
     assert np.array_equal(cb.integrator().render(cb, seed=1, spp=8),
                           cb.integrator().render(cb, seed=1, spp=8, flags=capi.FILM_NO_OCCLUDER_PRUNING))
+
+
+@pytest.mark.parametrize("n_lat,n_lon,accel", [(3, 4, "auto"), (8, 12, "auto"), (8, 12, "bvh_global")])
+def test_meshes_with_vertex_normals(mi, ob, capi, tmp_path, n_lat, n_lon, accel):
+    """interpolated shading normals (Mitsuba meshes with `vn`): a 16-triangle ball (brute force: a small scene with vertex
+    normals takes the _BIG kernel variant) and a 160-triangle one (LDS BVH, and the BVH read through the vector caches),
+    radiance and ultrasound mode, bit-exact / in tolerance against the oracle"""
+    from mesh_util import write_uv_sphere_obj
+    from test_oracle_transport import _lit_ball
+    nt = write_uv_sphere_obj(str(tmp_path / "ball.obj"), n_lat=n_lat, n_lon=n_lon, normals=True)
+    dif = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}}
+    sc = _lit_ball(mi, {"type": "obj", "filename": str(tmp_path / "ball.obj"), "bsdf": dif})
+    sc.integrator().max_depth = 3
+    if accel != "auto":
+        sc.accel = capi.ACCEL_BVH_GLOBAL
+    assert len(sc.flatten()["prims"]) == nt and sc.flatten()["vertex_normals"] is not None
+    img = mi.render(sc, seed=4)
+    ref, _ = oracle_render(ob, sc, 4, 4)
+    assert np.array_equal(img, ref) and img.mean() > 0.01
+    flat = _lit_ball(mi, {"type": "obj", "filename": str(tmp_path / "ball.obj"), "face_normals": True, "bsdf": dif})
+    assert not np.array_equal(mi.render(flat, seed=4), img)
+    # ultrasound mode: the shading normal is si.sh_frame.n of CustomIntegrator.py:340,345 and CustomBSDF.py:91
+    T = mi.ScalarTransform4f
+    us = mi.load_dict({"type": "scene",
+                       "integrator": {"type": "ultrasound_integrator", "max_depth": 4, "sampling_rate": 40e6, "frequency": 4e6, "sound_speed": 1500,
+                                      "attenuation": 0.3, "main_beam_angle": 20, "cutoff_angle": 35, "n_elements": 16, "pitch": 2e-4,
+                                      "time_samples": 3000, "angles": [-5.0, 5.0], "paths_per_ray": 80, "seed": 2},
+                       "sensor": {"type": "ultrasound_sensor", "to_world": T().look_at([0, 0, 0], [0, 0, 0.03], [0, 1, 0])},
+                       "ball": {"type": "obj", "filename": str(tmp_path / "ball.obj"),
+                                "to_world": T().translate([0.001, 0.0005, 0.02]).scale(0.006),
+                                "bsdf": {"type": "ultrasound_bsdf", "impedance": 5.0, "roughness": 0.6}}})
+    if accel != "auto":
+        us.accel = capi.ACCEL_BVH_GLOBAL
+    ui = us.integrator()
+    ui.simulate_acquisition_parallel(us)
+    want, _ = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 2, 80)
+    rel = np.linalg.norm(ui.channel_buf.astype(np.float64) - want) / np.linalg.norm(want.astype(np.float64))
+    assert rel <= 1e-3 and np.array_equal(ui.channel_buf != 0, want != 0) and np.abs(want).max() > 0

@@ -261,3 +261,38 @@ def test_occluder_pruning_changes_nothing(mi, ob, capi, bulb):
     a, _ = oracle_render(ob, cb, 1, 4)
     b, _ = oracle_render(ob, cb, 1, 4, flags=capi.FILM_NO_OCCLUDER_PRUNING)
     assert np.array_equal(a, b)
+
+
+def _lit_ball(mi, ball):
+    T = mi.ScalarTransform4f
+    return mi.load_dict({
+        "type": "scene", "integrator": {"type": "direct"},
+        "sensor": {"type": "perspective", "fov": 30, "near_clip": 0.1, "far_clip": 50,
+                   "to_world": T().look_at([0, 0, 5], [0, 0, 0], [0, 1, 0]),
+                   "film": {"type": "hdrfilm", "width": 48, "height": 48, "rfilter": {"type": "box"}},
+                   "sampler": {"type": "independent", "sample_count": 4}},
+        "ball": ball, "bulb": {"type": "point", "position": [3, 4, 6], "intensity": {"type": "rgb", "value": [60, 60, 60]}}})
+
+
+def test_vertex_normals_shade_smooth(mi, ob, tmp_path):
+    """Mitsuba meshes with vertex normals shade with si.sh_frame.n = normalize(b0 n0 + b1 n1 + b2 n2): a coarse UV sphere
+    (8 x 12) carrying its exact radial normals renders like the analytic sphere (position error of the tessellation only),
+    the same mesh with face normals (`face_normals`, or no `vn` in the file) is visibly faceted"""
+    from mesh_util import write_uv_sphere_obj
+    write_uv_sphere_obj(str(tmp_path / "ball_n.obj"), normals=True)
+    write_uv_sphere_obj(str(tmp_path / "ball_f.obj"), normals=False)
+    dif = {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.8, 0.8]}}
+    exact, _ = oracle_render(ob, _lit_ball(mi, {"type": "sphere", "center": [0, 0, 0], "radius": 1.0, "bsdf": dif}), 0, 4)
+    smooth_sc = _lit_ball(mi, {"type": "obj", "filename": str(tmp_path / "ball_n.obj"), "bsdf": dif})
+    f = smooth_sc.flatten()
+    assert f["vertex_normals"] is not None and f["vertex_normals"].shape == (len(f["prims"]), 9)
+    assert np.allclose(np.linalg.norm(f["vertex_normals"].reshape(-1, 3), axis=1), 1, atol=1e-6)
+    smooth, _ = oracle_render(ob, smooth_sc, 0, 4)
+    facet, _ = oracle_render(ob, _lit_ball(mi, {"type": "obj", "filename": str(tmp_path / "ball_f.obj"), "bsdf": dif}), 0, 4)
+    forced, _ = oracle_render(ob, _lit_ball(mi, {"type": "obj", "filename": str(tmp_path / "ball_n.obj"), "face_normals": True, "bsdf": dif}), 0, 4)
+    assert np.array_equal(forced, facet)                       # face_normals = true ignores the file's normals
+    inside = (exact.sum(axis=2) > 0) & (facet.sum(axis=2) > 0) & (smooth.sum(axis=2) > 0)
+    inside[:, :] &= np.roll(inside, 1, 0) & np.roll(inside, -1, 0) & np.roll(inside, 1, 1) & np.roll(inside, -1, 1)   # away from the silhouette
+    e_smooth = np.abs(smooth - exact)[inside].mean()
+    e_facet = np.abs(facet - exact)[inside].mean()
+    assert inside.sum() > 200 and e_smooth < 0.4 * e_facet and e_smooth < 0.03 * exact[inside].mean()

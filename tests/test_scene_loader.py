@@ -315,3 +315,19 @@ def test_cbox_with_boxes_scene(mi):
         if s.id() in ("largebox", "smallbox"):
             assert s.vertices.min() >= -1.0 - 1e-9 and s.vertices.max() <= 1.0 + 1e-9 and len(s.faces) == 12
             assert s.vertices[:, 1].min() == pytest.approx(-1.0, abs=1e-9)     # standing on the floor
+
+
+def test_testring_asset_carries_its_vertex_normals(mi):
+    sc = mi.load_file(scene_path("testring.xml"), res=16, spp=1)
+    f = sc.flatten()
+    vn, P = f["vertex_normals"], f["prims"]
+    assert vn is not None and vn.shape == (1154, 9)
+    ring = P["shape"] == 0
+    assert ring.sum() == 1152 and np.allclose(np.linalg.norm(vn[ring].reshape(-1, 3), axis=1), 1, atol=1e-5)
+    assert not vn[~ring].any()                                 # ground and lamp rectangles: face normals
+    # the vertex normals of the Onshape export are the face normal on the flat annuli and radial on the cylinders
+    n_face = P["g"][ring][:, 9:12]
+    cosang = np.einsum("ij,ikj->ik", n_face, vn[ring].reshape(-1, 3, 3))
+    assert cosang.min() > 0.99 and (cosang > 0.999999).all(axis=1).sum() > 500
+    twin = mi.load_file(scene_path("testring.xml"), res=16, spp=1, ring="meshes/ring.obj").flatten()
+    assert twin["vertex_normals"] is None                      # the procedural twin has no vn: face normals

@@ -2,7 +2,7 @@
 restatement written from the reference's Python -- NOT from oracle/oracle.cpp (see that module's header).
 
 Run in the build container (reads the reference's cbox OBJ quads as data):   python tests/golden/make_pinned.py
-Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k10_cbox_paths.npz
+Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k10_cbox_paths.npz, k11_meshes.npz
 
 K9  scenes:  'plate'       the scene USMain.py:26-90 builds (tilted plate 5 cm ahead, back wall at 1 m; integrator block :28-42)
              'sphere_box'  MitsubaScenes/Sphere_Box.xml:2-101 with the author-intent transforms
@@ -187,7 +187,75 @@ def make_k10():
           f"{(M >= 1e-3).mean() * 100:.1f} % with margin >= 1e-3")
 
 
+# ---- K11: triangle meshes ---------------------------------------------------------------------------------------------
+def ascii_ply(path):
+    lines = open(path).read().split("\n")
+    nv = int([l for l in lines if l.startswith("element vertex")][0].split()[2])
+    nf = int([l for l in lines if l.startswith("element face")][0].split()[2])
+    props = [l.split()[2] for l in lines[:lines.index("end_header")] if l.startswith("property") and "list" not in l]
+    body = lines[lines.index("end_header") + 1:]
+    v = np.array([[float(x) for x in body[i].split()] for i in range(nv)])[:, [props.index("x"), props.index("y"), props.index("z")]]
+    t = []
+    for i in range(nv, nv + nf):
+        idx = [int(x) for x in body[i].split()]
+        for k in range(2, idx[0]):
+            t.append((idx[1], idx[k], idx[k + 1]))
+    return v, np.array(t)
+
+
+def make_k11():
+    """(a) BASELINE config 1, the reference's own CPU-runnable case: scenes/simple.xml -- `direct` integrator (:5), perspective
+    sensor with the default 50 mm focal length looking from (0,-12,5) at (0,0,1.25), up z (:7-12), box filter (:17), teapot.ply
+    with diffuse (0.9, 0.9, 0) (:23-28), two `point` emitters of intensity 100 (:30-38); 64 x 64, samples 0..3 of every pixel.
+    (b) interpolated shading normals: a 16-triangle ball with exact radial vertex normals under one point light."""
+    here_meshes = os.path.join(os.path.dirname(HERE), "scenes", "meshes")
+    v, t = ascii_ply(os.path.join(here_meshes, "teapot.ply"))          # byte-identical copy of scenes/meshes/teapot.ply
+    teapot = rt.TriMesh(v, t, bsdf=dict(type="diffuse", reflectance=[0.9, 0.9, 0.0]))
+    lights = [rt.PointLight([3, -10, 6], [100, 100, 100]), rt.PointLight([-3, -10, -2], [100, 100, 100])]
+    res, seed, n_s = 64, 0, 4
+    diag = 2.0 * math.atan(math.sqrt(36.0 ** 2 + 24.0 ** 2) / (2.0 * 50.0))     # 50 mm on 36 x 24 mm film, diagonal axis
+    x_fov = math.degrees(2.0 * math.atan(math.tan(diag / 2.0) / math.sqrt(2.0)))   # aspect 1: width = diagonal / sqrt(2)
+    cam = dict(x_fov=x_fov, width=res, height=res, near=1e-2, far=1e4, to_world=rt.look_at([0, -12, 5], [0, 0, 1.25], [0, 0, 1]))
+    L = np.zeros((n_s, res, res, 3))
+    for s_ in range(n_s):
+        for y in range(res):
+            for x in range(res):
+                pix = y * res + x
+                uj = rt.rng4(pix, s_, 0, seed)
+                o, d, tmax = rt.perspective_ray(cam, (x + uj[0]) / res, (y + uj[1]) / res)
+                L[s_, y, x], _ = rt.path_radiance([teapot], lights, o, d, tmax, (pix, s_), seed, 2, 5)
+    # (b)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mesh_util", os.path.join(os.path.dirname(HERE), "mesh_util.py"))
+    mu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mu)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "ball.obj")
+        mu.write_uv_sphere_obj(path, n_lat=3, n_lon=4, normals=True)
+        vb = np.array([[float(x) for x in ln.split()[1:4]] for ln in open(path) if ln.startswith("v ")])
+        vn = np.array([[float(x) for x in ln.split()[1:4]] for ln in open(path) if ln.startswith("vn ")])
+        fb = np.array([[int(tok.split("/")[0]) - 1 for tok in ln.split()[1:4]] for ln in open(path) if ln.startswith("f ")])
+    ball = rt.TriMesh(vb, fb, bsdf=dict(type="diffuse", reflectance=[0.8, 0.7, 0.6]), vertex_normals=vn[fb])
+    resb = 24
+    camb = dict(x_fov=30.0, width=resb, height=resb, near=0.1, far=50.0, to_world=rt.look_at([0, 0, 5], [0, 0, 0], [0, 1, 0]))
+    lb = [rt.PointLight([3, 4, 6], [60, 60, 60])]
+    Lb = np.zeros((2, resb, resb, 3))
+    for s_ in range(2):
+        for y in range(resb):
+            for x in range(resb):
+                pix = y * resb + x
+                uj = rt.rng4(pix, s_, 0, 4)
+                o, d, tmax = rt.perspective_ray(camb, (x + uj[0]) / resb, (y + uj[1]) / resb)
+                Lb[s_, y, x], _ = rt.path_radiance([ball], lb, o, d, tmax, (pix, s_), 4, 3, 5)
+    meta = dict(simple=dict(res=res, seed=seed, samples=n_s, x_fov=x_fov), ball=dict(res=resb, seed=4, samples=2, n_lat=3, n_lon=4, max_depth=3))
+    np.savez_compressed(os.path.join(HERE, "k11_meshes.npz"), meta=json.dumps(meta), simple=L.astype(np.float32), ball=Lb)
+    print(f"k11_meshes.npz: simple.xml {n_s} x {res} x {res} samples, mean {L.mean():.5f}, lit {(L.sum(axis=3) > 0).mean() * 100:.1f} %; "
+          f"ball mean {Lb.mean():.5f}, lit {(Lb.sum(axis=3) > 0).mean() * 100:.1f} %")
+
+
 if __name__ == "__main__":
     for name, S in US_SCENES.items():
         make_k9(name, S)
     make_k10()
+    make_k11()

@@ -181,6 +181,55 @@ class Sphere:
         return p, n, vec(-local[1], local[0], 0.0) * (2.0 * math.pi)     # Sphere: dp_du = 2 pi (-y, x, 0)
 
 
+class TriMesh:
+    """Mitsuba `Mesh` (ply / obj shapes): triangles (p0, p1, p2), geometric normal normalize((p1 - p0) x (p2 - p0)), hit by
+    barycentrics (b1, b2); with vertex normals the shading normal is normalize(b0 n0 + b1 n1 + b2 n2)
+    (Mesh::compute_surface_interaction).  All triangles are tested at once with NumPy (Moeller-Trumbore in float64)."""
+
+    def __init__(self, vertices, triangles, bsdf=None, vertex_normals=None, emitter=None):
+        v = np.asarray(vertices, dtype=np.float64)
+        t = np.asarray(triangles, dtype=np.int64)
+        self.p0, self.e1, self.e2 = v[t[:, 0]], v[t[:, 1]] - v[t[:, 0]], v[t[:, 2]] - v[t[:, 0]]
+        n = np.cross(self.e1, self.e2)
+        self.ng = n / np.linalg.norm(n, axis=1, keepdims=True)
+        self.vn = None if vertex_normals is None else np.asarray(vertex_normals, dtype=np.float64)   # [nt, 3, 3]
+        self.bsdf, self.emitter = bsdf, emitter
+        self._last = -1
+
+    def intersect(self, o, d):
+        pvec = np.cross(d, self.e2)
+        det = np.einsum("ij,ij->i", self.e1, pvec)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / det
+            tvec = o - self.p0
+            u = np.einsum("ij,ij->i", tvec, pvec) * inv
+            qvec = np.cross(tvec, self.e1)
+            v = (qvec @ d) * inv
+            t = np.einsum("ij,ij->i", self.e2, qvec) * inv
+        ok = (det != 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0)
+        if not ok.any():
+            return None
+        tt = np.where(ok, t, np.inf)
+        k = int(np.argmin(tt))
+        self._last = k
+        # margin: distance of the barycentrics from the triangle's edges, and of the runner-up hit in t (shared edges)
+        others = np.delete(tt, k)
+        gap = (others.min() - tt[k]) / max(tt[k], 1e-30) if len(others) and np.isfinite(others.min()) else math.inf
+        return float(tt[k]), float(u[k]), float(v[k]), min(float(u[k]), float(v[k]), float(1.0 - u[k] - v[k]), 1e3 * gap + (1.0 if gap > 1e-6 else 0.0))
+
+    def interaction(self, o, d, t, u, v):
+        k = self._last
+        p = self.p0[k] + self.e1[k] * u + self.e2[k] * v
+        return p, self.ng[k], self.e1[k]
+
+    def shading_normal(self, u, v):
+        k = self._last
+        if self.vn is None:
+            return self.ng[k]
+        m = self.vn[k, 0] * (1.0 - u - v) + self.vn[k, 1] * u + self.vn[k, 2] * v
+        return normalize(m)
+
+
 def ray_intersect(shapes, o, d, tmax=math.inf):
     best = None
     for s in shapes:
@@ -404,6 +453,13 @@ def look_at(origin, target, up):
     return M
 
 
+class PointLight:
+    """Mitsuba `point` emitter: delta position, radiant intensity I -> incident radiance I / dist^2"""
+
+    def __init__(self, position, intensity):
+        self.position, self.intensity = np.asarray(position, dtype=np.float64), np.asarray(intensity, dtype=np.float64)
+
+
 def path_radiance(shapes, lights, o, d, tmax, key, seed, max_depth, rr_depth):
     """Mitsuba path.cpp sample(): emission with MIS, emitter sampling with a shadow ray, BSDF sampling, roulette.
     lights: the emitting Parallelograms (one `area` emitter each).  key = (a, b): draws come from rng4(a, b, block, seed)
@@ -421,9 +477,10 @@ def path_radiance(shapes, lights, o, d, tmax, key, seed, max_depth, rr_depth):
         shape, (t, u, v, edge_margin) = hit
         margin = min(margin, edge_margin)
         p, n, _ = shape.interaction(o, d, t, u, v)
+        ns = shape.shading_normal(u, v) if hasattr(shape, "shading_normal") else n      # si.sh_frame.n
         # ---- emitter hit: result += throughput * Le * mis   (area emitters are one-sided: eval = radiance if n . wi > 0)
         if shape.emitter is not None:
-            cos_l = -float(n @ d)
+            cos_l = -float(ns @ d)
             if cos_l > 0.0:
                 w = 1.0
                 if not prev_bsdf_delta:
@@ -433,14 +490,32 @@ def path_radiance(shapes, lights, o, d, tmax, key, seed, max_depth, rr_depth):
                 result = result + throughput * np.asarray(shape.emitter["radiance"]) * w
         if depth + 1 >= max_depth:
             break
-        frame = Frame(n)                                           # D13: coordinate_system(n)
+        frame = Frame(ns)                                          # D13: coordinate_system(sh_frame.n)
         wi = frame.to_local(-d)
         bsdf = shape.bsdf
         # ---- emitter sampling (only BSDFs with a smooth component)
+        L = None
         if bsdf["type"] == "diffuse" and nE > 0:
             ue = rng4(key[0], key[1], 1 + 2 * depth, seed)
             ei = min(int(ue[0] * nE), nE - 1)
             L = lights[ei]
+            if isinstance(L, PointLight):
+                dv = L.position - p
+                dist2 = float(dv @ dv)
+                dist = math.sqrt(dist2)
+                dl = dv / dist
+                wo = frame.to_local(dl)
+                if wi[2] > 0.0 and wo[2] > 0.0:
+                    f_cos = np.asarray(bsdf["reflectance"]) * (wo[2] / math.pi)
+                    so = spawn_origin(p, n, dl)
+                    sv = L.position - so
+                    sd = math.sqrt(float(sv @ sv))
+                    occ = ray_intersect(shapes, so, sv / sd, sd * (1.0 - SHADOW_EPSILON))
+                    if occ is None:   # delta emitter: no MIS; weight = I / dist^2 / (selection probability 1 / nE)
+                        result = result + throughput * f_cos * (L.intensity / dist2) * nE
+                    margin = min(margin, 1.0 if occ is None else occ[1][3])
+                L = None
+        if L is not None and bsdf["type"] == "diffuse" and nE > 0:
             q = L.p0 + L.e1 * ue[2] + L.e2 * ue[3]                 # D10: one uniform point on the parallelogram
             dv = q - p
             dist2 = float(dv @ dv)

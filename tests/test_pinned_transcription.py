@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, oracle_render, scene_path
-from pinned_util import SAFE, check_k10, check_k9_bins, check_k9_records, k9_scene, load_k10, load_k9
+from pinned_util import SAFE, check_k10, check_k11, check_k9_bins, check_k9_records, k9_scene, load_k10, load_k11, load_k9
 
 sys.path.insert(0, GOLDEN)
 
@@ -85,3 +85,30 @@ def test_k10_oracle_path_values(mi, ob):
     sc = mi.load_file(scene_path("cbox.xml"), res=meta["res"], spp=1, max_depth=meta["max_depth"], rfilter="box")
     worst = check_k10(z, meta, lambda s: oracle_render(ob, sc, meta["seed"], 1, sample_offset=s)[0])
     assert worst < 2e-4
+
+
+def test_k11_oracle_simple_xml_and_shading_normals(mi, ob, tmp_path):
+    """K11: BASELINE config 1 (scenes/simple.xml: teapot.ply, `direct`, two point emitters, box filter, default 50 mm lens) sample
+    by sample, and a 16-triangle ball with vertex normals (interpolated shading normal), against the float64 restatement"""
+    from mesh_util import write_uv_sphere_obj
+    z, meta = load_k11()
+    m = meta["simple"]
+    sc = mi.load_file(scene_path("simple.xml"), res=m["res"], spp=1)
+    assert sc.sensors()[0].x_fov == pytest.approx(m["x_fov"], abs=1e-9)
+    check_k11(z["simple"], lambda s: oracle_render(ob, sc, m["seed"], 1, sample_offset=s)[0], m["samples"])
+    b = meta["ball"]
+    write_uv_sphere_obj(str(tmp_path / "ball.obj"), n_lat=b["n_lat"], n_lon=b["n_lon"], normals=True)
+    check_k11(z["ball"], lambda s: oracle_render(ob, _ball_scene(mi, tmp_path, b), b["seed"], 1, sample_offset=s)[0], b["samples"])
+
+
+def _ball_scene(mi, tmp_path, b):
+    T = mi.ScalarTransform4f
+    return mi.load_dict({
+        "type": "scene", "integrator": {"type": "path", "max_depth": b["max_depth"]},
+        "sensor": {"type": "perspective", "fov": 30, "near_clip": 0.1, "far_clip": 50,
+                   "to_world": T().look_at([0, 0, 5], [0, 0, 0], [0, 1, 0]),
+                   "film": {"type": "hdrfilm", "width": b["res"], "height": b["res"], "rfilter": {"type": "box"}},
+                   "sampler": {"type": "independent", "sample_count": 1}},
+        "ball": {"type": "obj", "filename": str(tmp_path / "ball.obj"),
+                 "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}}},
+        "bulb": {"type": "point", "position": [3, 4, 6], "intensity": {"type": "rgb", "value": [60, 60, 60]}}})

@@ -502,7 +502,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const uint64_t film_px = (uint64_t)f->crop_w * f->crop_h;
     // default paths in flight per pass, measured on cbox 512^2 x 256 (one box): 2 / 4 / 8 / 16 / 32 / 64 Mi -> 9.55 / 8.56 / 8.14 / 7.92 /
     // 8.13 / 8.20 ms (fewer launch tails against cache residency of the ping-pong state)
-    uint64_t pass_paths = f->pass_paths ? f->pass_paths : (16u << 20);
+    // round 2, fused first launch: 2 / 4 / 8 / 16 / 32 / 64 Mi -> 9.09 / 8.07 / 7.65 / 7.37 / 7.31 / 7.39 ms; BVH scenes keep 16 Mi
+    const bool brute_scene = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
+    uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (32u << 20) : (16u << 20));
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
     s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
     NEED(c, npix_r * s_pass < 0xfffffc00ull);

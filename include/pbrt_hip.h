@@ -210,6 +210,13 @@ typedef struct pbrt_us_params {
                                        comes from pbrt_us_apply_pulse (not a reference quirk)  */
 #define PBRT_USQ_NO_FIRST_TABLES 0x200u /* diagnostic: every path walks the scene at its first bounce (same result) */
 #define PBRT_USQ_NO_FUSED_BOUNCES 0x400u /* diagnostic: one launch per bounce instead of one per pass */
+#define PBRT_USQ_FROZEN_DRAWS 0x800u  /* B1 (Dr.Jit variant): np.random.uniform is evaluated while dr.while_loop TRACES its body
+                                         (CustomIntegrator.py:153,173-174,219), so every bounce of a ray reuses the draws of its
+                                         first one: the RNG block of bounce b is block 0                              */
+#define PBRT_USQ_SIGNED_RR 0x1000u    /* B5 (Dr.Jit variant, :219-224): rr_prob = min(atten * amp, 1) without the abs, survive
+                                         iff u < rr_prob (strict), atten = survive ? atten / rr_prob : 0             */
+/* the Dr.Jit variant simulate_acquisition (CustomIntegrator.py:60-232), on top of PBRT_USQ_REFERENCE */
+#define PBRT_USQ_DRJIT_VARIANT (PBRT_USQ_CLAMP_TIME | PBRT_USQ_NO_TOF_ACCUM | PBRT_USQ_FROZEN_DRAWS | PBRT_USQ_SIGNED_RR)
 #define PBRT_USQ_REFERENCE                                                                \
     (PBRT_USQ_DIAG_SAMPLE | PBRT_USQ_REF_REFLECT | PBRT_USQ_UNIT_GGX_PDF | PBRT_USQ_DOUBLE_LOCAL | \
      PBRT_USQ_MIXED_FRAMES | PBRT_USQ_NEVER_ENTER)

@@ -1163,7 +1163,9 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     const float distance = h.t;                                                // :314
                     geo_len += distance;                                                       // :315
                     if (!(p->quirks & PBRT_USQ_NO_TOF_ACCUM)) tof += distance * inv_c;         // :316
-                    F4 u = rng4(ray_id, k, depth, seed);
+                    // B1 (Dr.Jit variant): the draws are constants of the traced loop body -- every bounce reuses block 0
+                    const uint32_t block = (p->quirks & PBRT_USQ_FROZEN_DRAWS) ? 0u : depth;
+                    F4 u = rng4(ray_id, k, block, seed);
                     uint32_t recv = std::min((uint32_t)(u.x * (float)NE), NE - 1);             // :319
                     V3 target = xf_point(p->sensor_to_world, v3(us_elem_x(p, recv), 0, 0));    // :320-321
                     V3 tv = target - si.p;
@@ -1184,7 +1186,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     if (M.type == PBRT_MAT_ULTRA) {
                         // intent arithmetic (A2 off): the micro-normal's second variate comes from a second block of the
                         // path's stream; u.w decides the roulette (:365) and must not steer the facet as well
-                        const float s1b = (p->quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, seed).x;
+                        const float s1b = (p->quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, block | 0x40000000u, seed).x;
                         UltraOut uo = ultra_core(M, p->quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
                         a_resp = uo.amp;
                         bpdf = uo.pdf;
@@ -1209,10 +1211,16 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     d = normalize(new_dir);                                                    // :358-359
                     o = offset_origin(si.p, si.n, d);
                     depth += 1;                                                                // :361
-                    float rr_prob = fminf(fabsf(atten * amp), 1.0f);                           // :364
                     bool survive = true;                                                       // (B5 repaired)
-                    if (u.w > rr_prob) survive = false;                                        // :365-366
-                    atten /= rr_prob;                                                          // :367
+                    if (p->quirks & PBRT_USQ_SIGNED_RR) {                                      // Dr.Jit variant :219-224
+                        const float rr_prob = fminf(atten * amp, 1.0f);
+                        survive = u.w < rr_prob;
+                        atten = survive ? atten / rr_prob : 0.0f;
+                    } else {
+                        const float rr_prob = fminf(fabsf(atten * amp), 1.0f);                 // :364
+                        if (u.w > rr_prob) survive = false;                                    // :365-366
+                        atten /= rr_prob;                                                      // :367
+                    }
                     bool within = dot(d, tn) >= cos_min;                                       // :371
                     active = active && within && (geo_len < p->max_path_len) && (depth < p->max_depth) && survive;  // :372-376
                 }

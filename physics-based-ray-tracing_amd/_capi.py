@@ -54,6 +54,9 @@ USQ_NO_TOF_ACCUM = 0x80
 USQ_NO_CARRIER = 0x100
 USQ_NO_FIRST_TABLES = 0x200
 USQ_NO_FUSED_BOUNCES = 0x400
+USQ_FROZEN_DRAWS = 0x800
+USQ_SIGNED_RR = 0x1000
+USQ_DRJIT_VARIANT = USQ_CLAMP_TIME | USQ_NO_TOF_ACCUM | USQ_FROZEN_DRAWS | USQ_SIGNED_RR
 USQ_REFERENCE = (USQ_DIAG_SAMPLE | USQ_REF_REFLECT | USQ_UNIT_GGX_PDF | USQ_DOUBLE_LOCAL
                  | USQ_MIXED_FRAMES | USQ_NEVER_ENTER)
 

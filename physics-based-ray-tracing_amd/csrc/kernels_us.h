@@ -196,7 +196,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             geo_len += distance;                                                       // :315
             const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
             if (!no_acc) tof += distance * a.inv_c;                                    // :316
-            F4 u = rng4(ray_id, k, depth, a.seed);
+            // B1 (Dr.Jit variant): the draws are constants of the traced loop body -- every bounce reuses block 0
+            const uint32_t block = (a.p.quirks & PBRT_USQ_FROZEN_DRAWS) ? 0u : depth;
+            F4 u = rng4(ray_id, k, block, a.seed);
             uint32_t recv = min((uint32_t)(u.x * (float)NE), NE - 1);                  // :319
             const bool tab = first && a.first_rx != nullptr;  // (ray, receive element) record of k_us_first
             float4 rx = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (M.type == PBRT_MAT_ULTRA) {
                 // intent arithmetic (no diagonal broadcast, A2 off): the micro-normal's second variate comes from a second
                 // block of the path's stream -- u.w also decides the roulette below and must not steer the facet as well
-                const float s1b = (a.p.quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, depth | 0x40000000u, a.seed).x;
+                const float s1b = (a.p.quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, block | 0x40000000u, a.seed).x;
                 UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
                 a_resp = uo.amp;
                 bpdf = uo.pdf;
@@ -274,9 +276,16 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                 }
                 d = normalize(new_dir);                                                // :358-359
                 o = offset_origin(si.p, si.n, d);
-                float rr_prob = fminf(fabsf(atten * amp), 1.0f);                       // :364
-                bool surv = !(u.w > rr_prob);                                          // :365-366
-                atten /= rr_prob;                                                      // :367
+                bool surv;
+                if (a.p.quirks & PBRT_USQ_SIGNED_RR) {                                 // Dr.Jit variant :219-224
+                    const float rr_prob = fminf(atten * amp, 1.0f);
+                    surv = u.w < rr_prob;
+                    atten = surv ? atten / rr_prob : 0.0f;
+                } else {
+                    const float rr_prob = fminf(fabsf(atten * amp), 1.0f);             // :364
+                    surv = !(u.w > rr_prob);                                           // :365-366
+                    atten /= rr_prob;                                                  // :367
+                }
                 bool within = dot(d, tn) >= a.cos_min;                                 // :371
                 survive = within && (geo_len < a.p.max_path_len) && (depth + 1 < a.p.max_depth) && surv;  // :372-376
             }

@@ -779,8 +779,8 @@ class UltraIntegrator(SamplingIntegrator):
         self.channel_buf = self._acquire(scene, self.quirks)
         return True
 
-    def simulate_acquisition(self, scene):  # CustomIntegrator.py:60-232 (Dr.Jit variant: App. B, B2/B3)
-        q = self.quirks | _capi.USQ_CLAMP_TIME | _capi.USQ_NO_TOF_ACCUM
+    def simulate_acquisition(self, scene):  # CustomIntegrator.py:60-232 (Dr.Jit variant: App. B -- B1 frozen draws, B2, B3, B5)
+        q = self.quirks | _capi.USQ_DRJIT_VARIANT
         self.channel_buf = self._acquire(scene, q).reshape(-1)
         return True
 

@@ -2,10 +2,13 @@
 restatement written from the reference's Python -- NOT from oracle/oracle.cpp (see that module's header).
 
 Run in the build container (reads the reference's cbox OBJ quads as data):   python tests/golden/make_pinned.py
-Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k10_cbox_paths.npz, k11_meshes.npz
+Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k9_us_two_plates.npz, k9_us_two_plates_drjit.npz,
+                     k10_cbox_paths.npz, k11_meshes.npz
 
 K9  scenes:  'plate'       the scene USMain.py:26-90 builds (tilted plate 5 cm ahead, back wall at 1 m; integrator block :28-42)
              'sphere_box'  MitsubaScenes/Sphere_Box.xml:2-101 with the author-intent transforms
+             'two_plates'  a narrow tilted plate in front of a wall: the scene whose SECOND-bounce echoes reach the receive
+                           elements (in both variants of the reference's loop: scalar and dr.while_loop)
     every (angle, element, path k) ray is traced by us_trace_single_ray with the draws rng4(ray, k, bounce, seed);
     the fixture holds every echo bin (index, summed pressure, summed envelope, the smallest decision margin among
     its contributors) and a set of single-bounce BSDF records (wi, n, sh_frame.s, s1, s2 -> wo, pdf, amplitude).
@@ -72,6 +75,19 @@ US_SCENES = {
                 dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
                 dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
         seed=7, ppr=3),
+    # second-bounce ECHOES: in the two scenes above a path that goes on never deposits again (plate: it leaves the cut-off cone
+    # or dies; sphere_box: it continues inside the sphere, from where no receive element is visible).  Here a narrow plate 2 cm
+    # ahead, 7.5 mm off axis and tilted by 12 degrees, in front of a wall at 5 cm: under the reference's arithmetic the
+    # "reflected" direction wi + 2 cos m, used as a world vector (quirks A5 / A9), heads on towards +z through the plate, hits the
+    # wall, and most wall points see the receive element past the plate's edge -- so the continuation direction (:358-359), the
+    # roulette division (:364-367) and the accumulated time of flight (:316) are in deposited VALUES
+    "two_plates": dict(
+        params=dict(max_depth=4, fs=50e6, frequency=3e6, sound_speed=1480.0, attenuation=0.1, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        look_at=([0, 0, 0], [0, 0, 0.05], [0, 1, 0]),
+        shapes=[dict(type="rectangle", to_world=Tr(0.0075, 0, 0.02) @ Ry(180 + 12) @ Sc(0.003, 0.01, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0, 0.05) @ Ry(180) @ Sc(0.05, 0.05, 1), impedance=7.8, roughness=0.5)],
+        seed=3, ppr=4),
 }
 
 
@@ -86,7 +102,7 @@ def build_shapes(desc):
     return out
 
 
-def make_k9(name, S):
+def make_k9(name, S, variant="scalar"):
     shapes = build_shapes(S["shapes"])
     P, seed, ppr = S["params"], S["seed"], S["ppr"]
     T = rt.look_at(*S["look_at"])
@@ -97,7 +113,7 @@ def make_k9(name, S):
         for e in range(NE):
             ray = a * NE + e
             for k in range(ppr):
-                out = rt.us_trace_single_ray(shapes, T, P, a, e, lambda dep: rt.rng4(ray, k, dep, seed))
+                out = rt.us_trace_single_ray(shapes, T, P, a, e, lambda dep: rt.rng4(ray, k, dep, seed), variant)
                 n_bounces += len(out)
                 for r in out:
                     recs.append(r)
@@ -122,11 +138,13 @@ def make_k9(name, S):
     for cond in (lambda r: r["tir"], lambda r: r["reflect"] and not r["tir"], lambda r: not r["reflect"], lambda r: r["depth"] >= 1):
         sel = [r for r in good if cond(r)]
         pick += sel[:: max(1, len(sel) // 16)][:16]
-    meta = dict(scene=name, params=P, look_at=S["look_at"], seed=seed, paths_per_ray=ppr, n_bounces=n_bounces,
+    tag = name if variant == "scalar" else f"{name}_{variant}"
+    meta = dict(scene=name, variant=variant, params=P, look_at=S["look_at"], seed=seed, paths_per_ray=ppr, n_bounces=n_bounces,
                 shapes=[{k: (np.asarray(v).tolist() if k in ("to_world", "center") else v) for k, v in d.items()} for d in S["shapes"]],
-                depth_histogram={str(d): sum(1 for r in recs if r["depth"] == d) for d in sorted({r["depth"] for r in recs})})
+                depth_histogram={str(d): sum(1 for r in recs if r["depth"] == d) for d in sorted({r["depth"] for r in recs})},
+                deposited_by_depth={str(d): sum(1 for r in recs if r["depth"] == d and r["deposited"]) for d in sorted({r["depth"] for r in recs})})
     np.savez_compressed(
-        os.path.join(HERE, f"k9_us_{name}.npz"), meta=json.dumps(meta),
+        os.path.join(HERE, f"k9_us_{tag}.npz"), meta=json.dumps(meta),
         bin_index=np.array(keys, np.int32).reshape(-1, 3), bin_pressure=np.array([bins[k]["p"] for k in keys]),
         bin_envelope=np.array([bins[k]["env"] for k in keys]), bin_envelope_abs=np.array([bins[k]["env_abs"] for k in keys]),
         bin_margin=np.array([bins[k]["margin"] for k in keys]), bin_count=np.array([bins[k]["n"] for k in keys], np.int32),
@@ -137,7 +155,7 @@ def make_k9(name, S):
         rec_new_dir=np.array([r["new_dir"] for r in pick]), rec_shape=np.array([r["shape"] for r in pick], np.int32),
         rec_depth=np.array([r["depth"] for r in pick], np.int32))
     safe = sum(1 for k in keys if bins[k]["margin"] >= 1e-2)
-    print(f"k9_us_{name}.npz: {n_bounces} bounces {meta['depth_histogram']}, {len(keys)} bins ({safe} with margin >= 1e-2), {len(pick)} BSDF records")
+    print(f"k9_us_{tag}.npz: {n_bounces} bounces {meta['depth_histogram']}, {len(keys)} bins ({safe} with margin >= 1e-2), {len(pick)} BSDF records")
 
 
 # ---- K10 --------------------------------------------------------------------------------------------------------------
@@ -257,5 +275,6 @@ def make_k11():
 if __name__ == "__main__":
     for name, S in US_SCENES.items():
         make_k9(name, S)
+    make_k9("two_plates", US_SCENES["two_plates"], "drjit")      # simulate_acquisition (CustomIntegrator.py:60-232)
     make_k10()
     make_k11()

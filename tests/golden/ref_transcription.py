@@ -324,8 +324,13 @@ def us_setup(P):
     return elem_x.astype(np.float64), angles_rad, tx_delay.astype(np.float32).astype(np.float64)    # :257
 
 
-def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws):
+def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant="scalar"):
     """draws(depth) -> (u_recv, s1, s2, u_rr): the four uniforms of one bounce (:319, :337, :365).
+    variant "scalar": _trace_single_ray of simulate_acquisition_parallel (:262-376, what USMain.py calls);
+    variant "drjit": the body of simulate_acquisition's dr.while_loop (:137-226), where it differs -- the draws are taken
+    while the loop body is TRACED (llvm_ad_mono, USMain.py:12), i.e. once per ray: every bounce sees draws(0) (:153,173-174,
+    219); tof is never updated, the echo time uses tof + distance / c of the current segment only (:165); the time bin is
+    clamped to [0, T - 1] instead of dropped (:191-193); roulette without the abs, strict <, atten zeroed on death (:219-224).
     -> list of per-bounce records."""
     n_angles, n_elements = len(P["angles_deg"]), int(P["n_elements"])
     fs_scalar, c_scalar, time_samples_scalar = float(P["fs"]), float(P["sound_speed"]), int(P["time_samples"])
@@ -350,17 +355,20 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws):
         p, n, dp_du = shape.interaction(ray_o, ray_d, t, u, v)
         sh = sh_frame_from_dp_du(n, dp_du)                      # si.sh_frame (n = geometric = shading normal here)
         si_wi = sh.to_local(-ray_d)                             # SurfaceInteraction::finalize: wi = to_local(-ray.d)
+        drjit = variant == "drjit"
         distance = t                                                                                # :314
         geo_len += distance                                                                         # :315
-        tof += distance / c_scalar                                                                  # :316
-        u_recv, s1, s2, u_rr = draws(depth)
+        if not drjit:
+            tof += distance / c_scalar                                                              # :316
+        u_recv, s1, s2, u_rr = draws(0 if drjit else depth)
         recv_idx = min(int(u_recv * n_elements), n_elements - 1)                                    # :319 rng.integers
         target_w = R @ vec(float(elem_x[recv_idx]), 0.0, 0.0) + tr                                  # :320-321
         sec_dir = normalize(target_w - p)                                                           # :322
         vis = ray_intersect(shapes, spawn_origin(p, n, sec_dir), sec_dir)                           # :324 (unbounded, B7)
         visible = vis is None                                                                       # :325
         atten *= math.exp(-P["attenuation"] * P["frequency"] * 1e-6 * distance / 8.686)             # :328
-        total_time = t0 + tof + math.sqrt(float((target_w - p) @ (target_w - p))) / c_scalar        # :329
+        tof_to_intersection = tof + distance / c_scalar if drjit else tof                           # drjit :165
+        total_time = t0 + tof_to_intersection + math.sqrt(float((target_w - p) @ (target_w - p))) / c_scalar   # :329
         phase = 2.0 * math.pi * P["frequency"] * total_time                                         # :330
         bs = ultra_bsdf_sample(shape.bsdf["impedance"], shape.bsdf["roughness"], si_wi, n, n, sh, s1, s2)   # :338
         cos_theta = float(n @ -ray_d)                                                               # :340
@@ -375,17 +383,24 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws):
         pressure_scalar = envelope * math.sin(phase)                                                # :348
         t_float = total_time * fs_scalar                                                            # :351
         t_idx = int(round(t_float))                                                                 # :352 (half to even)
+        if drjit:
+            t_idx = min(max(t_idx, 0), time_samples_scalar - 1)                                     # drjit :191-193
         deposited = 0 <= t_idx < time_samples_scalar and visible                                    # :353
         new_dir = sh.to_world(bs["wo"])                                                             # :358
         nd = normalize(new_dir)
         ray_o, ray_d_next = spawn_origin(p, n, nd), nd                                              # :359
         depth += 1                                                                                  # :361
-        rr_prob = min(abs(atten * amp), 1.0)                                                        # :364
-        survive = True                                                                              # (B5 repaired)
-        if u_rr > rr_prob:                                                                          # :365-366
-            survive = False
         atten_before_rr = atten
-        atten /= rr_prob                                                                            # :367
+        if drjit:
+            rr_prob = min(atten * amp, 1.0)                                                         # drjit :220
+            survive = u_rr < rr_prob                                                                # :221
+            atten = atten / rr_prob if survive else 0.0                                             # :224
+        else:
+            rr_prob = min(abs(atten * amp), 1.0)                                                    # :364
+            survive = True                                                                          # (B5 repaired)
+            if u_rr > rr_prob:                                                                      # :365-366
+                survive = False
+            atten /= rr_prob                                                                        # :367
         cos_min = math.cos(math.radians(P["cutoff_angle"]))                                         # :370
         within_angle = float(ray_d_next @ trans_normal_world) >= cos_min                            # :371
         path_ok = geo_len < 0.2                                                                     # :372

@@ -49,7 +49,7 @@ def check_k9_bins(z, meta, buf, carrier=True):
     got = np.asarray(buf, np.float64) * meta["paths_per_ray"]
     idx, margin = z["bin_index"], z["bin_margin"]
     safe = margin >= SAFE
-    assert safe.sum() >= 0.75 * len(idx) and safe.sum() >= 500
+    assert safe.sum() >= 0.7 * len(idx) and safe.sum() >= 500
     g = got[idx[:, 0], idx[:, 1], idx[:, 2]]
     # arrival: every well-conditioned echo lands in the bin the transcription says, and nothing lands elsewhere
     # except where an ill-conditioned decision may have moved it
@@ -90,6 +90,8 @@ def check_k9_records(z, meta, sample_fn):
         assert z["rec_reflect"].sum() >= 8 and (~z["rec_reflect"]).sum() >= 4 and z["rec_tir"].sum() >= 4
     else:
         assert (z["rec_depth"] >= 1).sum() >= 8 and z["rec_tir"].sum() >= 8
+    if meta["scene"] == "two_plates":   # the scene whose second-bounce echoes are deposited
+        assert int(meta["deposited_by_depth"]["1"]) >= 100
     return worst
 
 

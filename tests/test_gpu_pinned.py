@@ -10,7 +10,7 @@ from pinned_util import check_k10, check_k11, check_k9_bins, check_k9_records, k
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates"])
 def test_k9_hip_single_bounce_records(mi, capi, name):
     """UltraBSDF.sample (CustomBSDF.py:87-175) through the plugin API -> pbrt_bsdf_sample"""
     z, meta = load_k9(name)
@@ -23,7 +23,7 @@ def test_k9_hip_single_bounce_records(mi, capi, name):
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates"])
 @pytest.mark.parametrize("tables", [True, False])
 def test_k9_hip_echo_values(mi, capi, name, tables):
     """the whole acquisition (CustomIntegrator.py:235-376): arrival bins, pressures and bare envelopes of every echo,
@@ -92,3 +92,14 @@ def test_k11_hip_simple_xml_and_shading_normals(mi, tmp_path):
     write_uv_sphere_obj(str(tmp_path / "ball.obj"), n_lat=b["n_lat"], n_lon=b["n_lon"], normals=True)
     bsc = _ball_scene(mi, tmp_path, b)
     check_k11(z["ball"], lambda s: bsc.integrator().render(bsc, seed=b["seed"], spp=1, sample_offset=s), b["samples"])
+
+
+def test_k9_hip_drjit_variant(mi, capi):
+    """UltraIntegrator.simulate_acquisition (CustomIntegrator.py:60-232) through the plugin API against the transcription of
+    the dr.while_loop body"""
+    z, meta = load_k9("two_plates_drjit")
+    sc = k9_scene(mi, meta)
+    ui = sc.integrator()
+    assert ui.simulate_acquisition(sc) is True
+    buf = ui.channel_buf.reshape(ui.n_angles, ui.n_elements, ui.time_samples)
+    check_k9_bins(z, meta, buf, carrier=True)

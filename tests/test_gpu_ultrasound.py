@@ -55,12 +55,13 @@ def test_golden_channel_buffer(mi, scene, ppr, name):
 
 
 def test_drjit_variant_semantics(mi, ob, capi):
-    """simulate_acquisition (CustomIntegrator.py:60-232): clamped time bins, no tof accumulation; flat buffer."""
+    """simulate_acquisition (CustomIntegrator.py:60-232): draws frozen at trace time, clamped time bins, no tof accumulation,
+    signed roulette; flat buffer."""
     sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=128, seed=2)
     ui = sc.integrator()
     ui.simulate_acquisition(sc)
     assert ui.channel_buf.shape == (ui.n_angles * ui.n_elements * ui.time_samples,)
-    q = ui.quirks | capi.USQ_CLAMP_TIME | capi.USQ_NO_TOF_ACCUM
+    q = ui.quirks | capi.USQ_DRJIT_VARIANT
     ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc, q), 2, 128)
     check(ui.channel_buf.reshape(ref.shape), ref)
 

@@ -15,7 +15,7 @@ from pinned_util import SAFE, check_k10, check_k11, check_k9_bins, check_k9_reco
 sys.path.insert(0, GOLDEN)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates"])
 def test_k9_fixture_is_what_the_transcription_produces(name):
     """the committed fixture equals a fresh run of the transcription (first rays of every angle)"""
     import make_pinned as mp
@@ -50,7 +50,7 @@ def test_rng_of_the_transcription_is_the_librarys(ob, capi):
     assert np.all((u >= 0) & (u < 1)) and len(np.unique(u)) == u.size
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates"])
 def test_k9_oracle_single_bounce_records(ob, capi, name):
     z, meta = load_k9(name)
 
@@ -61,11 +61,12 @@ def test_k9_oracle_single_bounce_records(ob, capi, name):
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates"])
 def test_k9_oracle_echo_values(mi, ob, capi, name):
     """every echo of every path: arrival bin, pressure (CustomIntegrator.py:340-354) and, with the carrier off, the
-    envelope atten * amp * w_i * w_o alone; sphere_box has second-bounce echoes, so the continuation direction
-    (:358-359), the roulette division (:364-367) and the accumulated time of flight (:316) are in the values"""
+    envelope atten * amp * w_i * w_o alone; in two_plates the second-bounce echoes reach the receive elements (162 of
+    them), so the continuation direction (:358-359), the roulette division (:364-367) and the accumulated time of flight
+    (:316) are in deposited values (plate: paths end after one bounce; sphere_box: they go on inside the sphere, unseen)"""
     z, meta = load_k9(name)
     sc = k9_scene(mi, meta)
     ui = sc.integrator()
@@ -74,8 +75,8 @@ def test_k9_oracle_echo_values(mi, ob, capi, name):
     check_k9_bins(z, meta, buf, carrier=True)
     buf, _ = osc.us_acquire(ui.us_params(sc, ui.quirks | capi.USQ_NO_CARRIER), meta["seed"], meta["paths_per_ray"])
     check_k9_bins(z, meta, buf, carrier=False)
-    if name == "sphere_box":
-        assert int(meta["depth_histogram"].get("1", 0)) > 500
+    if name == "two_plates":
+        assert int(meta["deposited_by_depth"]["1"]) >= 100
 
 
 def test_k10_oracle_path_values(mi, ob):
@@ -112,3 +113,21 @@ def _ball_scene(mi, tmp_path, b):
         "ball": {"type": "obj", "filename": str(tmp_path / "ball.obj"),
                  "bsdf": {"type": "diffuse", "reflectance": {"type": "rgb", "value": [0.8, 0.7, 0.6]}}},
         "bulb": {"type": "point", "position": [3, 4, 6], "intensity": {"type": "rgb", "value": [60, 60, 60]}}})
+
+
+def test_k9_oracle_drjit_variant(mi, ob, capi):
+    """simulate_acquisition, the dr.while_loop variant (CustomIntegrator.py:60-232): draws frozen at trace time (every bounce of a
+    ray reuses its first draws), tof of the current segment only, clamped time bins, signed strict roulette"""
+    z, meta = load_k9("two_plates_drjit")
+    assert meta["variant"] == "drjit"
+    sc = k9_scene(mi, meta)
+    ui = sc.integrator()
+    osc = ob.OracleScene.from_scene(sc)
+    q = ui.quirks | capi.USQ_DRJIT_VARIANT
+    buf, _ = osc.us_acquire(ui.us_params(sc, q), meta["seed"], meta["paths_per_ray"])
+    check_k9_bins(z, meta, buf, carrier=True)
+    buf, _ = osc.us_acquire(ui.us_params(sc, q | capi.USQ_NO_CARRIER), meta["seed"], meta["paths_per_ray"])
+    check_k9_bins(z, meta, buf, carrier=False)
+    # it is a different estimator from the scalar variant's: second-bounce echoes land elsewhere (tof is not accumulated)
+    zs, _ = load_k9("two_plates")
+    assert not np.array_equal(z["bin_index"], zs["bin_index"]) and int(meta["deposited_by_depth"]["1"]) >= 100

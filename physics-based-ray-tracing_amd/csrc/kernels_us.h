@@ -245,21 +245,24 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (ok) {
                 float cos_theta = dot(si.ns, -d);                                      // :340 (si.sh_frame.n)
                 amp *= a_resp * cos_theta * fmaxf(bpdf, 1e-6f);                        // :341
-                float fd, carrier;
+                float fd = 0.0f, carrier = 0.0f;
                 uint32_t ci = 0xffffffffu;
                 if (tab) {
                     fd = rx.x;
                     carrier = rx.y;
                     ci = __float_as_uint(rx.z);
                 } else {
-                    float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);            // :286-287,345 (si.sh_frame.n)
-                    fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;          // :345
-                    // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
-                    carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
                     float tf = rintf(total_time * a.p.fs);                             // :351-352
                     if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
-                    if (tf >= 0.0f && tf < (float)T && visible)                        // :353
+                    if (tf >= 0.0f && tf < (float)T && visible) {                      // :353
                         ci = (ang * NE + recv) * T + (uint32_t)tf;                     // :354 (host checks it fits 32 bits)
+                        // the echo's weight and carrier only where an echo is deposited: acosf and sinf are a tenth of the
+                        // bounce, and e.g. every second bounce of the Sphere_Box phantom runs inside the sphere, unseen
+                        float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);        // :286-287,345 (si.sh_frame.n)
+                        fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;      // :345
+                        // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
+                        carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
+                    }
                 }
                 float pressure = atten * amp * fd * carrier;                           // :348
                 if (ci != 0xffffffffu) {

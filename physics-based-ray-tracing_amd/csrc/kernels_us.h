@@ -112,6 +112,25 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         agg_idx[t] = 0xffffffffu;
         agg_sum[t] = 0.0f;
     }
+    // the launch-uniform floats of the bounce are read from LDS (broadcast ds_read) instead of living in SGPRs: the kernel wants
+    // more scalars than the 102 it has and spills them into VGPR lanes (v_writelane / v_readlane).  Staging these 23 took the
+    // SGPR spills 105 -> 73 and config 3 14.16 -> 13.85 ms; staging the integer uniforms as well (64 spills) was slower, 13.92 ms.
+    __shared__ float uni[24];
+    if (threadIdx.x < 12) uni[threadIdx.x] = a.p.sensor_to_world[threadIdx.x];
+    if (threadIdx.x == 12) {
+        uni[12] = a.tn[0]; uni[13] = a.tn[1]; uni[14] = a.tn[2]; uni[15] = a.am; uni[16] = a.ac; uni[17] = a.cos_min;
+        uni[18] = a.katt; uni[19] = a.two_pi_f; uni[20] = a.inv_c; uni[21] = a.p.fs; uni[22] = a.p.max_path_len;
+    }
+#define U_M uni
+#define U_TN(k) uni[12 + (k)]
+#define U_AM uni[15]
+#define U_AC uni[16]
+#define U_COSMIN uni[17]
+#define U_KATT uni[18]
+#define U_2PIF uni[19]
+#define U_INVC uni[20]
+#define U_FS uni[21]
+#define U_MAXLEN uni[22]
     if (ACCEL == ACCEL_K_BRUTE)
         fill_tables_lds(a.sc, tab_lds, blockDim.x);  // ends with the barrier that also publishes the empty bins
     else
@@ -155,7 +174,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             ray_id = udiv_fast(home, a.div_ppr);
             k = a.path_first + (home - ray_id * a.ppr_pass);
             const uint32_t ang = udiv_fast(ray_id, a.div_ne), el = ray_id - ang * NE;
-            o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));           // :270,273
+            o = xf_point(U_M, v3(a.elem_x[el], 0.0f, 0.0f));           // :270,273
             d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);         // :271,273
             amp = 1.0f;
             atten = 1.0f;
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             k = a.path_first + (home - ray_id * a.ppr_pass);
         }
         const uint32_t ang = udiv_fast(ray_id, a.div_ne);
-        const V3 tn = {a.tn[0], a.tn[1], a.tn[2]};
+        const V3 tn = {U_TN(0), U_TN(1), U_TN(2)};
         Hit h;
         bool hit;
         if (first && a.first_hit) {  // shared first hit of the ray (k_us_first)
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             const float distance = h.t;                                                // :314
             geo_len += distance;                                                       // :315
             const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
-            if (!no_acc) tof += distance * a.inv_c;                                    // :316
+            if (!no_acc) tof += distance * U_INVC;                                    // :316
             // B1 (Dr.Jit variant): the draws are constants of the traced loop body -- every bounce reuses block 0
             const uint32_t block = (a.p.quirks & PBRT_USQ_FROZEN_DRAWS) ? 0u : depth;
             F4 u = rng4(ray_id, k, block, a.seed);
@@ -208,18 +227,18 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (tab) {
                 rx = a.first_rx[(size_t)ray_id * NE + recv];
             } else {
-                V3 target = xf_point(a.p.sensor_to_world, v3(a.elem_x[recv], 0.0f, 0.0f)); // :320-321
+                V3 target = xf_point(U_M, v3(a.elem_x[recv], 0.0f, 0.0f)); // :320-321
                 V3 tv = target - si.p;
                 float dist_recv = sqrtf(dot(tv, tv));
                 sec_dir = tv * (1.0f / dist_recv);                                     // :322
                 Hit hs;
                 visible = !scene_intersect<ACCEL, true>(a.sc, ls, offset_origin(si.p, si.n, sec_dir), sec_dir, K_INF,
                                                         &hs);                           // :324-325
-                float tof_hit = no_acc ? tof + distance * a.inv_c : tof;
-                total_time = a.tx[ray_id] + tof_hit + dist_recv * a.inv_c;             // :329
-                phase = a.two_pi_f * total_time;                                       // :330
+                float tof_hit = no_acc ? tof + distance * U_INVC : tof;
+                total_time = a.tx[ray_id] + tof_hit + dist_recv * U_INVC;             // :329
+                phase = U_2PIF * total_time;                                       // :330
             }
-            atten *= expf(a.katt * distance / 8.686f);                                 // :328
+            atten *= expf(U_KATT * distance / 8.686f);                                 // :328
             const pbrt_material M = tb.mats[P.material];
             // si.sh_frame as Mitsuba builds it (from dp_du, not coordinate_system(n)): si.wi, si.to_local, si.to_world
             const Frame fr = make_sh_frame(si.ns, si_dp_du<ACCEL != ACCEL_K_BRUTE>(P, si));
@@ -252,14 +271,14 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                     carrier = rx.y;
                     ci = __float_as_uint(rx.z);
                 } else {
-                    float tf = rintf(total_time * a.p.fs);                             // :351-352
+                    float tf = rintf(total_time * U_FS);                             // :351-352
                     if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
                     if (tf >= 0.0f && tf < (float)T && visible) {                      // :353
                         ci = (ang * NE + recv) * T + (uint32_t)tf;                     // :354 (host checks it fits 32 bits)
                         // the echo's weight and carrier only where an echo is deposited: acosf and sinf are a tenth of the
                         // bounce, and e.g. every second bounce of the Sphere_Box phantom runs inside the sphere, unseen
                         float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);        // :286-287,345 (si.sh_frame.n)
-                        fd = directivity_weight_i(sec_dir, tn, a.am, a.ac) * w_o;      // :345
+                        fd = directivity_weight_i(sec_dir, tn, U_AM, U_AC) * w_o;      // :345
                         // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
                         carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
                     }
@@ -289,8 +308,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                     surv = !(u.w > rr_prob);                                           // :365-366
                     atten /= rr_prob;                                                  // :367
                 }
-                bool within = dot(d, tn) >= a.cos_min;                                 // :371
-                survive = within && (geo_len < a.p.max_path_len) && (depth + 1 < a.p.max_depth) && surv;  // :372-376
+                bool within = dot(d, tn) >= U_COSMIN;                                 // :371
+                survive = within && (geo_len < U_MAXLEN) && (depth + 1 < a.p.max_depth) && surv;  // :372-376
             }
         }
     }
@@ -358,6 +377,16 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     }
     if (WP ? (tid & 63u) == 0 : tid == 0) a.seg_out[own] = out_off;
 }
+#undef U_M
+#undef U_TN
+#undef U_AM
+#undef U_AC
+#undef U_COSMIN
+#undef U_KATT
+#undef U_2PIF
+#undef U_INVC
+#undef U_FS
+#undef U_MAXLEN
 
 // First-bounce tables, one thread per (ray, receive element): the primary ray, its closest hit, and the occlusion test
 // towards the element -- the statements of k_us_bounce<FIRST> up to `visible`, once instead of once per path.

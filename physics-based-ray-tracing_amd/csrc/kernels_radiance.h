@@ -791,6 +791,94 @@ __global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const Rad
     }
 }
 
+// ---- k_regen: persistent waves with path regeneration (brute-force kernels) -------------------------------------------
+// The uniform primitive loop of the brute-force kernels does not care which paths share a wave, so nothing forces the
+// wavefront organisation on them: here a lane carries ONE path from the camera to its end in registers, and a lane whose
+// path ended takes the next unstarted path of its wave (one ballot + mbcnt per trip: the wave hands out the homes of its
+// share in order).  No path state in memory at all, no compaction, no barrier after the table staging, one launch per
+// pass; what a path leaves behind is its 16-byte Lhome record, and the film gather reads those in the same fixed order as
+// before, so the film does not change by a bit.  The grid is the number of waves the GPU holds at once (host:
+// regen_grid); wave w of W takes the 64-home groups w, w + W, w + 2 W, ... of the pass, so every wave samples the whole
+// film and the waves finish together (no queue in memory: same-word returning atomics cost 0.3 us each here).
+// Statistics: segments and shadow rays are counted per trip (wave-uniform popcounts); the depth rows come from a
+// histogram of the paths' final depths (one LDS atomic per finished path), live[d] = paths with more than d bounces.
+#ifndef REGEN_WG
+#define REGEN_WG 256
+#endif
+#ifndef REGEN_WAVES_PER_EU
+#define REGEN_WAVES_PER_EU 4
+#endif
+template <int ACCEL>
+__global__ __launch_bounds__(REGEN_WG, REGEN_WAVES_PER_EU) void k_regen(const RadArgs a) {
+    static_assert(ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "path regeneration: brute-force kernels only");
+    constexpr uint32_t W = REGEN_WG / 64;
+    __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
+    __shared__ uint32_t hist[W][MAX_DEPTH_STATS + 2];  // per wave: paths that ended after d + 1 bounces
+    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
+    const LdsScene ls = {nullptr, nullptr, nullptr};
+    const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
+    hist[wid][lane] = 0;  // MAX_DEPTH_STATS + 2 == 64
+    if (ACCEL == ACCEL_K_BRUTE)
+        fill_tables_lds(a.sc, tab_lds, REGEN_WG);  // ends with the only barrier of the kernel
+    else
+        __syncthreads();
+    const uint32_t gw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * W + wid)), GW = gridDim.x * W;
+    const Rsrc r_L = make_rsrc(a.Lhome, a.cap * 16u);
+    uint32_t q = 0;  // wave-uniform: homes of this wave's share handed out so far
+    bool live = false;
+    V3 o = {0, 0, 0}, d = {0, 0, 1}, thr = {0, 0, 0}, L = {0, 0, 0};
+    float eta = 1.0f, prev_pdf = -1.0f, tmax = K_INF;
+    uint32_t home = 0, ka = 0, kb = 0, depth = 0;
+    uint32_t nseg_w = 0, nshd_w = 0;
+#pragma unroll 1
+    for (;;) {
+        const unsigned long long need = __ballot(!live);
+        if (need) {  // uniform: hand the next homes of the share to the idle lanes
+            const uint32_t v = q + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t h0 = ((v >> 6) * GW + gw) * 64u + (v & 63u);
+            if (!live && h0 < a.n_paths) {
+                uint32_t px, py;
+                home = h0;
+                path_key<false>(a, home, &ka, &kb, &px, &py);
+                F4 uj = rng4(ka, kb, 0, a.seed);
+                float fx = (float)px + uj.x, fy = (float)py + uj.y;
+                camera_ray(a.cam, fx / (float)a.film_w, fy / (float)a.film_h, &o, &d, &tmax);
+                thr = {1, 1, 1};
+                L = {0, 0, 0};
+                eta = 1.0f;
+                prev_pdf = -1.0f;
+                depth = 0;
+                live = true;
+            }
+            q += (uint32_t)__popcll(need);
+        }
+        if (__ballot(live) == 0) break;  // the share is exhausted and every path of the wave has ended
+        bool did_seg = false, did_shadow = false;
+        if (live) {
+            const bool survive =
+                bounce_step<ACCEL>(a, tb, ls, r_L, depth, ka, kb, home, tmax, o, d, thr, L, eta, prev_pdf, did_seg, did_shadow);
+            if (!survive) atomicAdd(&hist[wid][min(depth, (uint32_t)MAX_DEPTH_STATS)], 1u);
+            live = survive;
+            ++depth;
+            tmax = K_INF;
+        }
+        nseg_w += (uint32_t)__popcll(__ballot(did_seg));
+        nshd_w += (uint32_t)__popcll(__ballot(did_shadow));
+    }
+    // statistics row of this wave: live[d] = paths that entered depth d = paths that ended after more than d bounces
+    unsigned long long *row = a.stats + gw;
+    const size_t stride = a.stat_stride;
+    if (lane == 0) {
+        row[0] += nseg_w;
+        row[stride] += nshd_w;
+    }
+    if (lane < min(a.max_depth, (uint32_t)MAX_DEPTH_STATS)) {
+        uint32_t n = 0;
+        for (uint32_t k = lane; k <= MAX_DEPTH_STATS; ++k) n += hist[wid][k];  // own wave's atomics: program order
+        row[(2 + lane) * stride] += n;
+    }
+}
+
 // column sums of the per-segment statistics: out[k] += sum_seg stats[k][seg].  grid (rows, REDUCE_SLICES): every block sums
 // one slice of a row and adds it to the row's total with one 64-bit atomic (out is zeroed by the caller; a single block
 // per row took 55 us for the 32 Ki rows of a 16 Mi-path pass, on the host's critical path of every call)

@@ -218,7 +218,22 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
     }
     pbrt_ctx *c = new pbrt_ctx();
     c->device = device;
+#ifdef PBRT_CU_MASK_PROBE  // diagnostic builds: run on a subset of the CUs (PBRT_CU_MASK = even | odd | low | pairs)
+    auto masked_stream = [&](hipStream_t *st) -> hipError_t {
+        const char *m = getenv("PBRT_CU_MASK");
+        if (!m) return hipStreamCreate(st);
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t b = 0; b < 256; ++b) {
+            bool on = !strcmp(m, "even") ? (b & 1u) == 0 : !strcmp(m, "odd") ? (b & 1u) == 1 : !strcmp(m, "low") ? b < 128
+                      : !strcmp(m, "altcu") ? ((b >> 5) & 1u) == 0 : !strcmp(m, "altse") ? ((b >> 3) & 1u) == 0 : !strcmp(m, "altcu2") ? ((b >> 6) & 1u) == 0 : !strcmp(m, "pairs") ? (b & 2u) == 0 : true;
+            if (on) mask[b >> 5] |= 1u << (b & 31u);
+        }
+        return hipExtStreamCreateWithCUMask(st, 8, mask);
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = masked_stream(&c->stream)) != hipSuccess ||
+#else
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&c->stream)) != hipSuccess ||
+#endif
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
         g_ctxless_error = std::string("device init: ") + hipGetErrorString(e);
         delete c;
@@ -582,6 +597,29 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
         const uint32_t fuse_plan = (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN;
         const uint32_t walk_from = (f->flags & PBRT_FILM_WALK_SET) ? ((f->flags >> 17) & 0xffu) : PBRT_DEFAULT_WALK_FROM;
+        if (brute && (f->flags & PBRT_FILM_REGEN)) {
+            // persistent waves with path regeneration (k_regen): one launch per pass, as many workgroups as the GPU holds at once
+            int per_cu = 0;
+            const void *fn = s->accel_kernel == ACCEL_K_BRUTE ? reinterpret_cast<const void *>(&k_regen<ACCEL_K_BRUTE>)
+                                                              : reinterpret_cast<const void *>(&k_regen<ACCEL_K_BRUTE_BIG>);
+            HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, REGEN_WG, 0));
+            const uint32_t wpw = REGEN_WG / 64;
+            uint32_t grid = (uint32_t)std::max(per_cu, 1) * (uint32_t)c->n_cu;
+            grid = std::min(grid, std::max(1u, n_rows / wpw));            // one statistics row per wave
+            grid = std::min(grid, div_up(a.n_paths, REGEN_WG));
+            a.depth = 0;
+            pass_e1 = c->event(n_ev + 1);
+            hipEvent_t e0 = c->event(n_ev);
+            if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+            n_ev += 2;
+            HIPCHK(c, hipEventRecord(e0, st));
+            if (s->accel_kernel == ACCEL_K_BRUTE)
+                hipLaunchKernelGGL(k_regen<ACCEL_K_BRUTE>, dim3(grid), dim3(REGEN_WG), 0, st, a);
+            else
+                hipLaunchKernelGGL(k_regen<ACCEL_K_BRUTE_BIG>, dim3(grid), dim3(REGEN_WG), 0, st, a);
+            HIPCHK(c, hipGetLastError());
+            ++launches;
+        } else
         for (uint32_t depth = 0; depth < f->max_depth;) {
             // bounces this launch walks: 2 at the depths of the fuse plan (brute-force kernels; the last bounce of a
             // path only looks for emitters, so it is never worth a launch slot of its own either)
@@ -709,6 +747,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
     const uint32_t plan = !brute_k ? 0u : ((f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN);
     radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth, &tot, &bb);
+    if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written
+        tot -= bb;
+        bb = S.samples * 12;
+        tot += bb;
+    }
     S.model_bytes = tot;
     S.bounce_model_bytes = bb;
     return PBRT_OK;

@@ -328,5 +328,13 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
         st = ctx.stats()
         assert np.array_equal(img, base), (hex(plan), walk)
         assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+    # k_regen: persistent waves, every lane walks one path to its end and then takes the next one (PBRT_FILM_REGEN): no path
+    # state in memory, one launch per pass -- and still the same film, segments, shadow rays and per-depth path counts
+    for pp in (0, 3 * base.shape[0] * base.shape[1] + 5):
+        img = integ.render(sc, seed=5, spp=6, flags=capi.FILM_REGEN, pass_paths=pp)
+        st = ctx.stats()
+        assert np.array_equal(img, base), pp
+        assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+        assert st["bounce_launches"] == st["passes"] and st["bounce_model_bytes"] == 12 * st["samples"]
     # passes: a short last pass and the fused first launch
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)

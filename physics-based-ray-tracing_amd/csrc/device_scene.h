@@ -415,6 +415,85 @@ DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float h
 #ifndef PBRT_BVH_RING
 #define PBRT_BVH_RING 0
 #endif
+// Two-phase ("while-while") traversal: a lane walks inner nodes until it holds a leaf to test or has finished, and the
+// primitives of the held leaves are tested when EVERY lane of the wave has got that far.  The primitive test is the long
+// part of a step (60 VALU per primitive against 40 for the two boxes of a node) and in the one-loop form below it ran in
+// almost every trip for the few lanes that happened to stand at a leaf (later bounces of the ring: 19 % of the lanes active
+// per VALU instruction).  Holding a leaf delays the update of `best`, so a lane may visit a node more than it would have:
+// still conservative, and the result does not depend on the visiting order (ties in t go to the lowest primitive id).
+#ifndef PBRT_BVH_ONE_LOOP
+template <bool ANY, typename NodeP, typename PrimP, typename IdP>
+DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
+    const BoxRay br = make_box_ray(o, d);
+    uint32_t node = 0;
+    unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
+    bool found = false, done = false;
+    float best = tmax;
+    uint32_t leaf_a = 0, leaf_b = 0;  // held leaf references (BVH_LEAF set, so never 0)
+    for (;;) {
+        while (!done && leaf_a == 0) {
+            const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
+            float t0, t1;
+            const bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0],
+                                     nodes[node].hi0[1], nodes[node].hi0[2], br, best, &t0);
+            const bool h1 = box_test(nodes[node].lo1[0], nodes[node].lo1[1], nodes[node].lo1[2], nodes[node].hi1[0],
+                                     nodes[node].hi1[1], nodes[node].hi1[2], br, best, &t1);
+            const bool l0 = h0 && (c0 & BVH_LEAF), l1 = h1 && (c1 & BVH_LEAF);
+            leaf_a = l0 ? c0 : (l1 ? c1 : 0u);
+            leaf_b = (l0 && l1) ? c1 : 0u;
+            const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
+            if (i0 || i1) {
+                const bool both = i0 && i1;
+                const bool near0 = both ? (t0 <= t1) : i0;
+                trail = (trail << 1) | (both ? 1ull : 0ull);
+                node = near0 ? c0 : c1;
+                continue;
+            }
+            // pop: climb until a level with a pending sibling
+            while ((trail & 1ull) == 0ull) {
+                if (trail == 0ull) {
+                    done = true;
+                    break;
+                }
+                trail >>= 1;
+                node = nodes[node].parent;
+            }
+            if (!done) {
+                const uint32_t p = nodes[node].parent;
+                node = (nodes[p].c0 == node) ? nodes[p].c1 : nodes[p].c0;
+                trail ^= 1ull;
+            }
+        }
+        if (leaf_a == 0) break;  // this lane has finished (the wave leaves the loop when every lane has)
+#pragma unroll 1
+        for (int side = 0; side < 2; ++side) {
+            const uint32_t c = side ? leaf_b : leaf_a;
+            if (c == 0) break;
+            const uint32_t first = c & 0x07ffffffu, count = (c >> 27) & 15u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t slot = first + k;
+                float t, u, v;
+                if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
+                    if (ANY) return true;
+                    const uint32_t id = prim_ids[slot];
+                    if (!found || t < best || (t == best && id < h->prim)) {
+                        best = t;
+                        h->t = t;
+                        h->u = u;
+                        h->v = v;
+                        h->prim = id;
+                        h->slot = slot;
+                        found = true;
+                    }
+                }
+            }
+        }
+        leaf_a = 0;
+        leaf_b = 0;
+    }
+    return found;
+}
+#else
 template <bool ANY, typename NodeP, typename PrimP, typename IdP>
 DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
     const BoxRay br = make_box_ray(o, d);
@@ -510,6 +589,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
     }
     return found;
 }
+#endif  // PBRT_BVH_ONE_LOOP
 
 // ---- surface interaction ------------------------------------------------------------------------
 struct SI {

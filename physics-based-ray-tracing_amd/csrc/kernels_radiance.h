@@ -153,6 +153,25 @@ DEV uint32_t region_index(uint32_t xx, uint32_t yy, uint32_t rw, uint32_t tile_r
     return yy < tile_rows ? (yy >> 3) * (8u * rw) + (xx << 3) + (yy & 7u) : yy * rw + xx;
 }
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch), and consecutive regions are consecutive pixels of a row: on a film
+// that is 8 segments wide (4096 px) XCD k would render column stripe k of EVERY row -- the XCDs with the spheres in their stripe
+// finish last (cbox 4096^2: the later bounces 18-40 % slower than on the 512^2 film with the same paths).  Rotating the regions
+// inside every aligned group of 8 by the sum of the base-8 digits of the group index deals every stripe to every XCD in turn.
+// A permutation of [0, n): the last, partial group is left alone.
+DEV uint32_t xcd_swizzle(uint32_t b, uint32_t n) {
+#ifdef PBRT_NO_XCD_SWIZZLE
+    return b;
+#else
+    if ((b | 7u) >= n) return b;
+    uint32_t g = b >> 3, rot = 0;
+    while (g) {
+        rot += g;
+        g >>= 3;
+    }
+    return (b & ~7u) | ((b + rot) & 7u);
+#endif
+}
+
 template <bool TILED>
 DEV void path_key(const RadArgs &a, uint32_t home, uint32_t *ka, uint32_t *kb, uint32_t *px, uint32_t *py) {
     if (a.key_mode == 0) {
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     __shared__ uint32_t wave_shd[2][SEG / 64];
     __shared__ uint32_t wave_mid[2][NB > 1 ? SEG / 64 : 1];  // NB = 2: paths that went on to the launch's second bounce
 
-    const uint32_t seg = blockIdx.x;  // region index
+    const uint32_t seg = xcd_swizzle(blockIdx.x, gridDim.x);  // region index
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t REGION = rad_region_segs(ACCEL) * SEG;
     constexpr bool TILED = ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS;  // 8 x 8 pixel tiles per wave (path_key)
@@ -633,7 +652,7 @@ __global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const Rad
     constexpr uint32_t SEG = SEG_BRUTE, W = SEG / 64;
     __shared__ uint32_t wave_tot[2][W], wave_seg[2][W], wave_shd[2][W], wave_mid[2][W];  // double-buffered over the bounces
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x, wid = tid >> 6, base = seg * SEG;
+    const uint32_t seg = xcd_swizzle(blockIdx.x, gridDim.x), tid = threadIdx.x, wid = tid >> 6, base = seg * SEG;
     uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, SEG) : 0u) : a.seg_in[seg];
     if (cnt_in == 0) {  // uniform across the workgroup
         if (tid == 0) a.seg_out[seg] = 0;

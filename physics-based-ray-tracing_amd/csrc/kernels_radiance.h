@@ -379,11 +379,12 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
 // Cornell box, 20 % at depth 4, so the host fuses the early pairs only: rad_fuse_plan).  Same arithmetic per bounce, same
 // RNG keys: the film does not change.  The loop costs registers, so these variants take the 128-VGPR budget.
 template <bool FIRST, int ACCEL, int NB = 1>
-// two-bounce variants at the 128-register budget (72 VGPRs, no scratch, 6 resident waves per SIMD).  At the 64-register
-// budget (-DFUSED_WAVES_PER_EU=8: 8 waves, 5 spilled VGPRs) the Cornell box gains 0.8 % (7.41 -> 7.35 ms) but every launch
-// writes 700 MB of scratch on top of its 1.5 GB of state (PMC WRITE_SIZE 1.46 x the model instead of 1.06 x): not taken
+// two-bounce variants of ACCEL_K_BRUTE at the 64-register budget: 8 waves per SIMD with ONE spilled VGPR (a 4-byte scratch store
+// and load per bounce).  Without the budget the kernel takes 67 VGPRs = 7 waves, i.e. three 512-thread workgroups per CU instead of
+// four: 6.99 - 7.03 -> 6.82 - 6.85 ms on the Cornell box.  (Before -fno-slp-vectorize the same budget spilled 5 VGPRs and wrote
+// 700 MB of scratch per launch for +0.8 %: not taken then.)
 #ifndef FUSED_WAVES_PER_EU
-#define FUSED_WAVES_PER_EU 4
+#define FUSED_WAVES_PER_EU 8
 #endif
 __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUTE ? FUSED_WAVES_PER_EU : 4) : seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
     static_assert(NB == 1 || ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "fused bounces: brute-force kernels only");

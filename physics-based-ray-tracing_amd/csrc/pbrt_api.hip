@@ -416,7 +416,7 @@ int pbrt_scene_destroy(pbrt_scene *s) {
 // Depths at which a launch of the brute-force kernels walks two bounces (bit d: bounces d and d + 1).  Measured on the
 // Cornell box; pbrt_film_desc.flags can override it per call (PBRT_FILM_FUSE_PLAN).
 #ifndef PBRT_DEFAULT_FUSE_PLAN
-#define PBRT_DEFAULT_FUSE_PLAN 0x1u
+#define PBRT_DEFAULT_FUSE_PLAN 0x15u
 #endif
 // Depth from which one launch walks every remaining bounce of a pass (k_walk; 0xff: never).  PBRT_FILM_WALK_FROM overrides.
 #ifndef PBRT_DEFAULT_WALK_FROM

@@ -7,7 +7,7 @@ import numpy as np
 import pbrt_amd as mi
 capi = __import__("importlib").import_module("physics-based-ray-tracing_amd._capi")
 plans = [int(x, 16) for x in sys.argv[1:]] or [0x0, 0x1, 0x4, 0x5, 0x15, 0x3f]
-sc = mi.load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/scenes/cbox.xml"), res=512, spp=256)
+sc = mi.load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/scenes", os.environ.get("FUSE_SCENE", "cbox.xml")), res=512, spp=256)
 integ = sc.integrator()
 ctx = mi.default_context()
 ref = None

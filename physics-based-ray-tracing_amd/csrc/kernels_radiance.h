@@ -58,10 +58,14 @@ __host__ __device__ constexpr uint32_t rad_region_segs(int accel) {
 __host__ __device__ constexpr uint32_t seg_threads(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH : SEG_BRUTE;
 }
+#ifndef BIG_WAVES_PER_EU
+#define BIG_WAVES_PER_EU 8
+#endif
 __host__ __device__ constexpr uint32_t seg_waves_per_eu(int accel) {
-    // _BIG (tables in global memory, cone code): 4 spilled VGPRs at the 64-register budget, and the budget itself is
-    // worth nothing to these kernels (cbox at 4 waves per SIMD: 8.69 against 8.77 ms), so it gets 128
-    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH / 256 : (accel == ACCEL_K_BRUTE_BIG ? 4 : SEG_WAVES_PER_EU);
+    // _BIG (tables in global memory, cone code): round 1 gave these kernels the 128-register budget (4 spilled VGPRs at 64 then).
+    // Built without SLP vectorisation the one-bounce variants fit 58 - 64 VGPRs and the two-bounce ones spill 4 - 8 at 64;
+    // four 512-thread workgroups per CU instead of three: cone_room 512^2 x 256 10.21 -> 9.82 ms
+    return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? SEG_BVH / 256 : (accel == ACCEL_K_BRUTE_BIG ? BIG_WAVES_PER_EU : SEG_WAVES_PER_EU);
 }
 // BVH kernels compact per WAVE: every wave owns REGION / (SEG / 64) slots of its workgroup's region, walks its own
 // live prefix 64 paths at a time and packs its survivors with ballot + mbcnt alone -- no barrier after the scene is
@@ -386,7 +390,7 @@ template <bool FIRST, int ACCEL, int NB = 1>
 #ifndef FUSED_WAVES_PER_EU
 #define FUSED_WAVES_PER_EU 8
 #endif
-__global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUTE ? FUSED_WAVES_PER_EU : 4) : seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
+__global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUTE ? FUSED_WAVES_PER_EU : BIG_WAVES_PER_EU) : seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
     static_assert(NB == 1 || ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "fused bounces: brute-force kernels only");
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];

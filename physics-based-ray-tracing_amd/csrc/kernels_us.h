@@ -54,10 +54,13 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 // about 95 VGPRs: 4 waves per SIMD run it without spills.  (While same-word global atomics dominated the kernel the
 // spilling 8-wave build was the fastest -- 2.83 / 2.98 / 3.06 ms at 8 / 6 / 4 waves; with the echoes summed in LDS
 // it is the other way round: 1.17 / 1.10 / 1.11 ms on Sphere_Box 5 x 64 x 65536.)
+// Round 2 (-fno-slp-vectorize, uniforms in LDS): what counts is whole 512-thread workgroups per CU, 2 waves per SIMD each --
+// 96 VGPRs (5 waves) still means two workgroups, 80 VGPRs with 4 of them spilled means three: config 3
+// 13.2 / 13.2 / 11.9 / 14.4 ms at 4 / 5 / 6 / 8 waves (8: 30 spilled).
 #define US_AGG_LOG2 8
 #define US_AGG_BINS (1u << US_AGG_LOG2)
 #ifndef US_WAVES_PER_EU
-#define US_WAVES_PER_EU 4
+#define US_WAVES_PER_EU 6
 #endif
 __host__ __device__ constexpr uint32_t us_waves_per_eu(int accel) {
     return (accel == ACCEL_K_BVH_GLOBAL || accel == ACCEL_K_BVH_LDS) ? seg_waves_per_eu(accel) : US_WAVES_PER_EU;

@@ -937,8 +937,9 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
 #ifndef US_PASS_PATHS
 // paths in flight per pass.  Config 3 (268 M paths), one launch per bounce: 8 / 16 / 32 / 64 Mi -> 13.1 / 12.7 / 13.0 /
 // 13.2 ms; with all bounces of a pass in one launch the survivors are re-read while still cached and smaller passes
-// win: 2 / 4 / 6 / 8 / 12 / 16 / 32 / 64 Mi -> 13.1 / 9.8 / 8.4 / 8.1 / 8.2 / 8.5 / 9.0 / 8.7 ms
-#define US_PASS_PATHS (8u << 20)
+// win: 2 / 4 / 6 / 8 / 12 / 16 / 32 / 64 Mi -> 13.1 / 9.8 / 8.4 / 8.1 / 8.2 / 8.5 / 9.0 / 8.7 ms.  Later in round 2 (Mitsuba's
+// shading frame: 1.96 segments per path; three workgroups per CU): 4 / 8 / 16 / 32 Mi -> 13.26 / 11.89 / 11.61 / 12.20 ms
+#define US_PASS_PATHS (16u << 20)
 #endif
     const uint64_t pass_paths = US_PASS_PATHS;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));

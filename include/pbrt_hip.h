@@ -166,7 +166,8 @@ typedef struct pbrt_film_desc {
                                        pass (brute-force kernels: the workgroup that owns a segment carries its survivors on; \
                                        0 = one launch per pass, 0xff = never).  Unset: the library's default.  Same film either way */
 #define PBRT_FILM_WALK_FROM(d) (PBRT_FILM_WALK_SET | (((d) & 0xffu) << 17))
-#define PBRT_FILM_REGEN 8u /* experiment: brute-force scenes, persistent waves with path regeneration (one launch per pass) */
+#define PBRT_FILM_REGEN 8u /* diagnostic: brute-force scenes, persistent waves with path regeneration (k_regen: no path state in \
+                             memory, one launch per pass; same film, measured slower than the wavefront launches) */
 #define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
                                            instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
                                            and the lone area light are left out of it) -- same film if the pruning is right */

@@ -57,6 +57,8 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
 // Round 2 (-fno-slp-vectorize, uniforms in LDS): what counts is whole 512-thread workgroups per CU, 2 waves per SIMD each --
 // 96 VGPRs (5 waves) still means two workgroups, 80 VGPRs with 4 of them spilled means three: config 3
 // 13.2 / 13.2 / 11.9 / 14.4 ms at 4 / 5 / 6 / 8 waves (8: 30 spilled).
+#define US_N_STATE 11  // origin, direction, amp, atten, tof, geo_len, home
+DEV uint32_t us_state_voff(uint32_t slot) { return (slot >> 6) * (64u * US_N_STATE * 4u) + (slot & 63u) * 4u; }
 #define US_AGG_LOG2 8
 #define US_AGG_BINS (1u << US_AGG_LOG2)
 #ifndef US_WAVES_PER_EU
@@ -147,8 +149,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     // fast: Sphere_Box has 20 % of them left after the first bounce and none after the second; the 8 empty launches up
     // to max_depth cost 5 us each per pass).  Config 3: 10.1 ms with one launch per bounce, 9.1 with bounces >= 1
     // fused, 8.6 with all of them.
-    const float *in = a.in;
-    float *out = a.out;
+    // path state: tiles of 64 slots x 11 rows like the radiance kernels' (kernels_radiance.h state_voff), read and written through
+    // buffer descriptors: the row offset k * 256 is an immediate of the instruction, no 64-bit address arithmetic and no
+    // pointer pair per array in SGPRs (this kernel spills scalars)
+    Rsrc r_in = make_rsrc(a.in, cap * (US_N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (US_N_STATE * 4u));
     uint32_t depth = a.depth;
     uint32_t out_off, ns_acc;
     for (;;) {  // bounce loop: a single trip unless a.fuse
@@ -184,14 +188,15 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             tof = 0.0f;
             geo_len = 0.0f;                                                            // :276-279
         } else {
-            const float *s = in + slot;
-            o = {s[0 * cap], s[1 * cap], s[2 * cap]};
-            d = {s[3 * cap], s[4 * cap], s[5 * cap]};
-            amp = s[6 * cap];
-            atten = s[7 * cap];
-            tof = s[8 * cap];
-            geo_len = s[9 * cap];
-            home = __float_as_uint(s[10 * cap]);
+            const uint32_t v4 = us_state_voff(slot);
+            constexpr uint32_t row = STATE_ROW_BYTES;
+            o = {bld(r_in, v4 + 0 * row, 0), bld(r_in, v4 + 1 * row, 0), bld(r_in, v4 + 2 * row, 0)};
+            d = {bld(r_in, v4 + 3 * row, 0), bld(r_in, v4 + 4 * row, 0), bld(r_in, v4 + 5 * row, 0)};
+            amp = bld(r_in, v4 + 6 * row, 0);
+            atten = bld(r_in, v4 + 7 * row, 0);
+            tof = bld(r_in, v4 + 8 * row, 0);
+            geo_len = bld(r_in, v4 + 9 * row, 0);
+            home = __float_as_uint(bld(r_in, v4 + 10 * row, 0));
             ray_id = udiv_fast(home, a.div_ppr);
             k = a.path_first + (home - ray_id * a.ppr_pass);
         }
@@ -338,18 +343,19 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         }
     }
     if (survive) {
-        float *s = out + base + out_off + off + prefix;
-        s[0 * cap] = o.x;
-        s[1 * cap] = o.y;
-        s[2 * cap] = o.z;
-        s[3 * cap] = d.x;
-        s[4 * cap] = d.y;
-        s[5 * cap] = d.z;
-        s[6 * cap] = amp;
-        s[7 * cap] = atten;
-        s[8 * cap] = tof;
-        s[9 * cap] = geo_len;
-        s[10 * cap] = __uint_as_float(home);
+        const uint32_t v4 = us_state_voff(base + out_off + off + prefix);
+        constexpr uint32_t row = STATE_ROW_BYTES;
+        bst(r_out, v4 + 0 * row, 0, o.x);
+        bst(r_out, v4 + 1 * row, 0, o.y);
+        bst(r_out, v4 + 2 * row, 0, o.z);
+        bst(r_out, v4 + 3 * row, 0, d.x);
+        bst(r_out, v4 + 4 * row, 0, d.y);
+        bst(r_out, v4 + 5 * row, 0, d.z);
+        bst(r_out, v4 + 6 * row, 0, amp);
+        bst(r_out, v4 + 7 * row, 0, atten);
+        bst(r_out, v4 + 8 * row, 0, tof);
+        bst(r_out, v4 + 9 * row, 0, geo_len);
+        bst(r_out, v4 + 10 * row, 0, __uint_as_float(home));
     }
     out_off += total;
     if (!WP && tid == 0)
@@ -367,9 +373,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     // of a workgroup share the CU's vector L1, so no invalidate), then everybody has finished reading the old input
     __threadfence_block();
     if (!WP) __syncthreads();
-    const float *nxt_in = out;
-    out = const_cast<float *>(in);
-    in = nxt_in;
+    const Rsrc nxt_in = r_out;
+    r_out = r_in;
+    r_in = nxt_in;
     cnt_in = out_off;
     ++depth;
     }  // bounce loop

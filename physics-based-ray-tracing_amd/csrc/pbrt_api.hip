@@ -946,6 +946,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
     const uint32_t REGION = us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
+    NEED(c, (uint64_t)cap * US_N_STATE * 4 < 0xffffffffull);  // the state tiles are addressed through 32-bit buffer offsets
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     const uint32_t n_own = nseg * us_owners_per_region(s->accel_kernel);  // live counters / statistics rows

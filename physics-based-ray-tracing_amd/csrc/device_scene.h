@@ -421,9 +421,27 @@ DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float h
 // almost every trip for the few lanes that happened to stand at a leaf (later bounces of the ring: 19 % of the lanes active
 // per VALU instruction).  Holding a leaf delays the update of `best`, so a lane may visit a node more than it would have:
 // still conservative, and the result does not depend on the visiting order (ties in t go to the lowest primitive id).
+#ifdef PBRT_BVH_PROBE  // diagnostic builds: how many of a wave's traversal trips does a lane use?  (tools/bvh_probe.py)
+__device__ unsigned long long g_bvh_probe[8];  // closest hit: wave trips x 64, lane trips (node walk), same for primitive tests; any hit: +4
+#define BVH_PROBE_FIRST_LANE() \
+    (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u)
+#endif
 #ifndef PBRT_BVH_ONE_LOOP
 template <bool ANY, typename NodeP, typename PrimP, typename IdP>
 DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
+#ifdef PBRT_BVH_PROBE
+    uint32_t pn1 = 0, pw1 = 0, pn2 = 0, pw2 = 0;
+    struct ProbeFlush {
+        uint32_t &n1, &w1, &n2, &w2;
+        __device__ ~ProbeFlush() {
+            const int b = ANY ? 4 : 0;
+            atomicAdd(&g_bvh_probe[b + 0], (unsigned long long)w1);
+            atomicAdd(&g_bvh_probe[b + 1], (unsigned long long)n1);
+            atomicAdd(&g_bvh_probe[b + 2], (unsigned long long)w2);
+            atomicAdd(&g_bvh_probe[b + 3], (unsigned long long)n2);
+        }
+    } probe_flush{pn1, pw1, pn2, pw2};
+#endif
     const BoxRay br = make_box_ray(o, d);
     uint32_t node = 0;
     unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
@@ -432,6 +450,10 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
     uint32_t leaf_a = 0, leaf_b = 0;  // held leaf references (BVH_LEAF set, so never 0)
     for (;;) {
         while (!done && leaf_a == 0) {
+#ifdef PBRT_BVH_PROBE
+            ++pn1;
+            if (BVH_PROBE_FIRST_LANE()) pw1 += 64;
+#endif
             const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
             float t0, t1;
             const bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0],
@@ -473,6 +495,10 @@ DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float
             for (uint32_t k = 0; k < count; ++k) {
                 const uint32_t slot = first + k;
                 float t, u, v;
+#ifdef PBRT_BVH_PROBE
+                ++pn2;
+                if (BVH_PROBE_FIRST_LANE()) pw2 += 64;
+#endif
                 if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
                     if (ANY) return true;
                     const uint32_t id = prim_ids[slot];

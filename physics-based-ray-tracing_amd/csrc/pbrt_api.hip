@@ -757,6 +757,17 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     return PBRT_OK;
 }
 
+#ifdef PBRT_BVH_PROBE  // diagnostic builds only (tools/bvh_probe.py); not part of the ABI
+extern "C" int pbrt_debug_bvh_probe(unsigned long long *out, int reset) {
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bvh_probe), 64) != hipSuccess) return PBRT_E_DEVICE;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_bvh_probe), z, 64) != hipSuccess) return PBRT_E_DEVICE;
+    }
+    return PBRT_OK;
+}
+#endif
+
 extern "C" {
 
 int pbrt_render_radiance_dev(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {

@@ -168,6 +168,8 @@ typedef struct pbrt_film_desc {
 #define PBRT_FILM_WALK_FROM(d) (PBRT_FILM_WALK_SET | (((d) & 0xffu) << 17))
 #define PBRT_FILM_REGEN 8u /* diagnostic: brute-force scenes, persistent waves with path regeneration (k_regen: no path state in \
                              memory, one launch per pass; same film, measured slower than the wavefront launches) */
+#define PBRT_FILM_NO_HIT_POOL 0x10u /* diagnostic: BVH scenes, bounces >= 1 through k_bounce (shading in whatever lanes are left after the \
+                                    closest hit) instead of k_bounce_pool (closest hits first, shading in full waves) */
 #define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
                                            instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
                                            and the lone area light are left out of it) -- same film if the pruning is right */

@@ -26,6 +26,7 @@ FILTER_BOX, FILTER_TENT, FILTER_GAUSSIAN = 0, 1, 2
 FILM_RAW_ACCUM = 1
 FILM_NO_REPACK = 2
 FILM_NO_OCCLUDER_PRUNING = 4
+FILM_NO_HIT_POOL = 0x10  # diagnostic: BVH scenes without k_bounce_pool
 FILM_REGEN = 8  # diagnostic: brute-force scenes, persistent waves with path regeneration, one launch per pass (k_regen)
 FILM_FUSE_PLAN_SET = 0x80
 

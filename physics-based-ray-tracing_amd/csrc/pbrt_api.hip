@@ -464,6 +464,13 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32
     }
 }
 
+// k_bounce_pool keeps its hit stacks (POOL_BYTES) in LDS beside the scene image: scenes whose image leaves no room for them
+// stay with k_bounce for every bounce
+static bool hit_pool_fits(const pbrt_scene *s) {
+    if (s->accel_kernel == ACCEL_K_BVH_GLOBAL) return true;
+    return s->accel_kernel == ACCEL_K_BVH_LDS && (size_t)s->lds_bytes + POOL_BYTES + 1024 <= s->ctx->lds_limit;
+}
+
 static int set_lds_attr(pbrt_scene *s) {
     if (s->accel_kernel != ACCEL_K_BVH_LDS) return PBRT_OK;
     pbrt_ctx *c = s->ctx;
@@ -472,6 +479,9 @@ static int set_lds_attr(pbrt_scene *s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (hit_pool_fits(s))
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce_pool<ACCEL_K_BVH_LDS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<true, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<false, ACCEL_K_BVH_LDS>),
@@ -650,7 +660,12 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 HIPCHK(c, hipEventRecord(e0, st));
             }
             const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
-            if (walk) {
+            if (!brute && depth >= 1 && !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s)) {
+                if (s->accel_kernel == ACCEL_K_BVH_GLOBAL)
+                    hipLaunchKernelGGL(k_bounce_pool<ACCEL_K_BVH_GLOBAL>, dim3(nseg_pass), dim3(SEG_BVH), 0, st, a);
+                else
+                    hipLaunchKernelGGL(k_bounce_pool<ACCEL_K_BVH_LDS>, dim3(nseg_pass), dim3(SEG_BVH), s->lds_bytes, st, a);
+            } else if (walk) {
                 if (depth == 0)
                     launch_walk<true>(s, a, nseg_pass, nb);
                 else

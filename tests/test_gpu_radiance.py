@@ -282,6 +282,18 @@ def test_bvh_scene_at_scale_queue_and_repack(mi, ob, capi):
     assert np.array_equal(img[150:174], ref) and img.mean() > 0
     st = mi.default_context().stats()
     assert st["samples"] == 320 * 320 * 12 and st["live"][0] == st["samples"] and st["live"][2] < st["live"][1] < st["live"][0]
+    # bounces >= 1 run in k_bounce_pool (a stream of closest-hit queries, shading in full waves) unless switched off: same
+    # film, same segments, shadow rays and per-depth path counts either way, with the LDS image and with the tree in global memory
+    img0 = integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL)
+    st0 = mi.default_context().stats()
+    assert np.array_equal(img0, img)
+    assert list(st0["live"]) == list(st["live"]) and st0["segments"] == st["segments"] and st0["shadow_rays"] == st["shadow_rays"]
+    assert np.array_equal(integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL | capi.FILM_NO_REPACK), img)
+    scg = mi.load_file(scene_path("testring.xml"), res=320, spp=12)
+    scg.accel = capi.ACCEL_BVH_GLOBAL
+    ig = scg.integrator()
+    assert np.array_equal(ig.render(scg, seed=2, spp=12), img)
+    assert np.array_equal(ig.render(scg, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL), img)
 
 
 def test_bvh_repack_with_a_short_last_pass(mi, ob, capi):

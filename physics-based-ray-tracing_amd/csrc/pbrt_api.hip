@@ -492,13 +492,20 @@ static int set_lds_attr(pbrt_scene *s) {
 // Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
 // A launch that walks two bounces (fuse plan bit d) keeps its paths in registers between them: the survivors of bounce d
 // are neither written nor read back, only the survivors of bounce d + 1 are.
+// hit_pool (k_bounce_pool, BVH scenes, bounces >= 1): every ray reads origin and direction (24 B), the paths that hit something
+// read their full state again; the hits per depth are not counted separately, so the model charges the full state only to the
+// paths that go on (a lower bound: the achieved figure is understated, not flattered).
 static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, uint64_t samples, uint64_t film_px,
-                                 uint32_t passes, uint32_t fuse_plan, uint32_t max_depth, uint64_t *total, uint64_t *bounce) {
+                                 uint32_t passes, uint32_t fuse_plan, uint32_t max_depth, bool hit_pool, uint64_t *total,
+                                 uint64_t *bounce) {
     uint64_t b = 0;
     for (uint32_t d = 0; d < nd;) {
         const uint32_t nb = (d < 8 && ((fuse_plan >> d) & 1u) && d + 1 < max_depth && d + 1 < nd) ? 2u : 1u;
         uint64_t in = live[d], next = (d + nb < nd) ? live[d + nb] : 0;
-        if (d > 0) b += in * (N_STATE * 4);  // state read
+        if (d > 0 && hit_pool)
+            b += in * 24 + next * (N_STATE * 4);
+        else if (d > 0)
+            b += in * (N_STATE * 4);  // state read
         b += next * (N_STATE * 4);            // compacted survivors written
         b += (in - next) * 12;                // radiance of the paths that ended (at either bounce of the launch)
         d += nb;
@@ -761,7 +768,8 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
     const uint32_t plan = !brute_k ? 0u : ((f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN);
-    radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth, &tot, &bb);
+    radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth,
+                         !brute_k && !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s), &tot, &bb);
     if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written
         tot -= bb;
         bb = S.samples * 12;

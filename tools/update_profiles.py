@@ -27,7 +27,7 @@ def per_dispatch(sub, ctr):
     f = max(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)  # newest run
     tot, n = {}, {}
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != ctr or kernel + "<" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != ctr or not any(k + "<" in r["Kernel_Name"] for k in (kernel, kernel + "_pool")):
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])

@@ -45,6 +45,7 @@ __host__ __device__ constexpr uint32_t rad_region_segs(int accel);
 __host__ __device__ constexpr uint32_t us_region_segs(int) { return REGION_SEGS_US; }
 #define N_STATE 15
 #define MAX_DEPTH_STATS 62
+#define HIT_ROW0 (2 + MAX_DEPTH_STATS)  // k_bounce_pool: statistics rows HIT_ROW0 + d = rays of depth d that hit something
 
 // ACCEL_K_BRUTE      uniform primitive loop (scalar loads) + shading tables staged in LDS; every table <= 32 entries,
 //                    no analytic cones (device_scene.h brute_intersect CONES)
@@ -906,6 +907,7 @@ __global__ __launch_bounds__(SEG_BVH, SEG_BVH / 256) void k_bounce_pool(const Ra
         srow[0] += ns_acc;
         srow[stride] += nh_acc;
         srow[(2 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += live_acc;
+        srow[(HIT_ROW0 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += ns_acc;  // hits of this depth (byte model)
         // the last wave to finish publishes the region's survivor count (LDS atomics of one CU are ordered)
         if (atomicAdd(&q_done, 1u) == W - 1) a.seg_out[seg] = atomicAdd(&q_out, 0u);
     }

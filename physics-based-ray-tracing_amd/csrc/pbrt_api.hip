@@ -492,18 +492,17 @@ static int set_lds_attr(pbrt_scene *s) {
 // Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
 // A launch that walks two bounces (fuse plan bit d) keeps its paths in registers between them: the survivors of bounce d
 // are neither written nor read back, only the survivors of bounce d + 1 are.
-// hit_pool (k_bounce_pool, BVH scenes, bounces >= 1): every ray reads origin and direction (24 B), the paths that hit something
-// read their full state again; the hits per depth are not counted separately, so the model charges the full state only to the
-// paths that go on (a lower bound: the achieved figure is understated, not flattered).
+// hits (k_bounce_pool launches, BVH scenes, bounces >= 1; else nullptr): hits[d] = rays of depth d that hit something.  Every ray
+// reads its origin and direction (24 B), a path that hit something reads its full state.
 static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, uint64_t samples, uint64_t film_px,
-                                 uint32_t passes, uint32_t fuse_plan, uint32_t max_depth, bool hit_pool, uint64_t *total,
-                                 uint64_t *bounce) {
+                                 uint32_t passes, uint32_t fuse_plan, uint32_t max_depth, const unsigned long long *hits,
+                                 uint64_t *total, uint64_t *bounce) {
     uint64_t b = 0;
     for (uint32_t d = 0; d < nd;) {
         const uint32_t nb = (d < 8 && ((fuse_plan >> d) & 1u) && d + 1 < max_depth && d + 1 < nd) ? 2u : 1u;
         uint64_t in = live[d], next = (d + nb < nd) ? live[d + nb] : 0;
-        if (d > 0 && hit_pool)
-            b += in * 24 + next * (N_STATE * 4);
+        if (d > 0 && hits)
+            b += in * 24 + hits[d] * (N_STATE * 4);
         else if (d > 0)
             b += in * (N_STATE * 4);  // state read
         b += next * (N_STATE * 4);            // compacted survivors written
@@ -559,19 +558,24 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t *offs = repack ? (uint32_t *)c->buf("seg_offs", (size_t)n_own * 4) : nullptr;
     uint32_t *quota = repack ? (uint32_t *)c->buf("seg_quota", 64) : nullptr;
     float *acc = (float *)c->buf("film_acc", film_px * 16);
-    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + 2 * MAX_DEPTH_STATS) * 8);
     const uint32_t n_rows = nseg * rad_rows_per_region(s->accel_kernel);         // statistics rows
     // statistics rows in use: segments, shadow rays, one per depth (cleared and reduced per call: keep it to what the call touches)
     const uint32_t stat_rows = 2 + (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS);
     const size_t segstats_bytes = (size_t)stat_rows * n_rows * 8;  // reduced at the end
-    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", (size_t)(2 + MAX_DEPTH_STATS) * n_rows * 8);
+    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", (size_t)(2 + 2 * MAX_DEPTH_STATS) * n_rows * 8);
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
+    // k_bounce_pool launches also count the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
+    const bool hit_pool = (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) &&
+                          !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s);
+    const uint32_t hit_rows = hit_pool ? stat_rows - 2 : 0;
     if (repack && (!stC || !segC || !offs || !quota)) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     HIPCHK(c, hipMemsetAsync(acc, 0, film_px * 16, st));
-    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
+    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + 2 * MAX_DEPTH_STATS) * 8, st));
     HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
+    if (hit_rows) HIPCHK(c, hipMemsetAsync(segstats + (size_t)HIT_ROW0 * n_rows, 0, (size_t)hit_rows * n_rows * 8, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     size_t n_ev = 0;
     hipEvent_t pass_e1 = nullptr;
@@ -667,7 +671,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 HIPCHK(c, hipEventRecord(e0, st));
             }
             const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
-            if (!brute && depth >= 1 && !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s)) {
+            if (hit_pool && depth >= 1) {
                 if (s->accel_kernel == ACCEL_K_BVH_GLOBAL)
                     hipLaunchKernelGGL(k_bounce_pool<ACCEL_K_BVH_GLOBAL>, dim3(nseg_pass), dim3(SEG_BVH), 0, st, a);
                 else
@@ -742,8 +746,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                        (uint32_t)((f->flags & PBRT_FILM_RAW_ACCUM) ? 1 : 0));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
-    unsigned long long hstats[2 + MAX_DEPTH_STATS];
+    unsigned long long hstats[2 + 2 * MAX_DEPTH_STATS];
     hipLaunchKernelGGL(k_reduce_stats, dim3(stat_rows, REDUCE_SLICES), dim3(256), 0, st, segstats, n_rows, (size_t)n_rows, dstats);
+    if (hit_rows)
+        hipLaunchKernelGGL(k_reduce_stats, dim3(hit_rows, REDUCE_SLICES), dim3(256), 0, st, segstats + (size_t)HIT_ROW0 * n_rows, n_rows,
+                           (size_t)n_rows, dstats + HIT_ROW0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -769,7 +776,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
     const uint32_t plan = !brute_k ? 0u : ((f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN);
     radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth,
-                         !brute_k && !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s), &tot, &bb);
+                         hit_pool ? hstats + HIT_ROW0 : nullptr, &tot, &bb);
     if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written
         tot -= bb;
         bb = S.samples * 12;

@@ -139,11 +139,12 @@ def test_occluder_pruning_changes_nothing_on_the_device(mi, ob, capi, bulb):
                           cb.integrator().render(cb, seed=1, spp=8, flags=capi.FILM_NO_OCCLUDER_PRUNING))
 
 
-@pytest.mark.parametrize("n_lat,n_lon,accel", [(3, 4, "auto"), (8, 12, "auto"), (8, 12, "bvh_global")])
+@pytest.mark.parametrize("n_lat,n_lon,accel", [(3, 4, "auto"), (8, 12, "auto"), (8, 12, "bvh_global"), (20, 24, "auto"), (26, 26, "auto")])
 def test_meshes_with_vertex_normals(mi, ob, capi, tmp_path, n_lat, n_lon, accel):
     """interpolated shading normals (Mitsuba meshes with `vn`): a 16-triangle ball (brute force: a small scene with vertex
     normals takes the _BIG kernel variant) and a 160-triangle one (LDS BVH, and the BVH read through the vector caches),
-    radiance and ultrasound mode, bit-exact / in tolerance against the oracle"""
+    radiance and ultrasound mode, bit-exact / in tolerance against the oracle.  912 triangles: an LDS image (~94 KB) that
+    leaves room for k_bounce_pool's hit stacks; 1 300 triangles: one (~133 KB) that does not, so bounces >= 1 stay with k_bounce"""
     from mesh_util import write_uv_sphere_obj
     from test_oracle_transport import _lit_ball
     nt = write_uv_sphere_obj(str(tmp_path / "ball.obj"), n_lat=n_lat, n_lon=n_lon, normals=True)

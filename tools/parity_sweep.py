@@ -1,0 +1,56 @@
+"""One-off confidence sweep on the GPU box (not part of the suites): random scenes like tests/test_gpu_random_scenes.py with many more
+seeds, larger films and more samples -- film against the oracle bit for bit, for every accelerator and launch-structure switch.
+usage: python tools/parity_sweep.py [first_seed n_seeds]"""
+import os, sys, tempfile, pathlib
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import numpy as np
+import pbrt_amd as mi
+import conftest
+from test_gpu_random_scenes import _random_scene
+capi = __import__("importlib").import_module("physics-based-ray-tracing_amd._capi")
+from oracle import binding as ob   # the checker: test infrastructure, never the product path
+ob.build()
+def set_film(scene, w=96, h=64):
+    f = scene.sensors()[0].film()
+    f.width, f.height, f.crop = w, h, (0, 0, w, h)
+
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+tmp = pathlib.Path(tempfile.mkdtemp())
+shapes = [(3, 4, 0, 0), (5, 10, 12, 0), (2, 3, 500, 0), (4, 4, 1100, 0), (2, 4, 0, 3), (3, 5, 300, 4), (0, 2, 2500, 0)]
+bad = 0
+for k in range(n):
+    seed = first + k
+    ns, nr, nt, nc = shapes[k % len(shapes)]
+    sc = _random_scene(mi, tmp, seed, ns, nr, nt, nc)
+    integ, sens = sc.integrator(), sc.sensors()[0]
+    integ.max_depth = 3 + k % 5
+    set_film(sc)
+    spp = 9 + k % 7
+    osc = ob.OracleScene.from_scene(sc)
+    ref = osc.render(sens.camera(), integ._film_desc(sc, sens, seed, spp), n_threads=8)
+    n_prims = len(sc.flatten()["prims"])
+    variants = [("default", 0, None)]
+    if n_prims <= 32:
+        variants += [("plan0", capi.film_fuse_plan(0), None), ("plan3f", capi.film_fuse_plan(0x3f), None), ("regen", capi.FILM_REGEN, None),
+                     ("bvh", 0, capi.ACCEL_BVH), ("bvh_global", 0, capi.ACCEL_BVH_GLOBAL)]
+    else:
+        variants += [("no_pool", capi.FILM_NO_HIT_POOL, None), ("no_repack", capi.FILM_NO_REPACK, None), ("global", 0, capi.ACCEL_BVH_GLOBAL),
+                     ("global_no_pool", capi.FILM_NO_HIT_POOL, capi.ACCEL_BVH_GLOBAL)]
+    res = []
+    for name, fl, acc in variants:
+        s2 = sc
+        if acc is not None:
+            s2 = _random_scene(mi, tmp, seed, ns, nr, nt, nc)
+            s2.accel = acc
+            s2.integrator().max_depth = integ.max_depth
+            set_film(s2)
+        img = s2.integrator().render(s2, seed=seed, spp=spp, flags=fl, pass_paths=(0 if k % 2 else 96 * 64 * 4 + 11))
+        ok = bool(np.array_equal(img, ref))
+        bad += not ok
+        res.append(f"{name}:{'ok' if ok else 'DIFF'}")
+    print(f"seed {seed}: {n_prims:5d} prims depth {integ.max_depth} spp {spp} mean {ref.mean():.4f}  " + " ".join(res), flush=True)
+print("mismatches:", bad)
+sys.exit(1 if bad else 0)

@@ -383,8 +383,9 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
 // NB: bounces walked by one launch (1 or 2; brute-force kernels only).  With NB = 2 a path that survives its first bounce
 // of the launch goes straight on in registers -- no state write, no compaction, no state read in between -- and the
 // lanes whose paths ended idle through the second bounce (87 % / 83 % of the lanes stay busy at depths 0 / 2 of the
-// Cornell box, 20 % at depth 4, so the host fuses the early pairs only: rad_fuse_plan).  Same arithmetic per bounce, same
-// RNG keys: the film does not change.  The loop costs registers, so these variants take the 128-VGPR budget.
+// Cornell box, 20 % at depth 4 -- where the second bounce is the last one and only looks for emitters).  Same arithmetic
+// per bounce, same RNG keys: the film does not change.  Which depths start a two-bounce launch is the host's fuse plan
+// (pbrt_api.hip PBRT_DEFAULT_FUSE_PLAN: every pair).
 template <bool FIRST, int ACCEL, int NB = 1>
 // two-bounce variants of ACCEL_K_BRUTE at the 64-register budget: 8 waves per SIMD with ONE spilled VGPR (a 4-byte scratch store
 // and load per bounce).  Without the budget the kernel takes 67 VGPRs = 7 waves, i.e. three 512-thread workgroups per CU instead of

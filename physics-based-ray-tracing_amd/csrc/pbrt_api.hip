@@ -414,7 +414,8 @@ int pbrt_scene_destroy(pbrt_scene *s) {
 // radiance mode driver
 // ------------------------------------------------------------------------------------------------
 // Depths at which a launch of the brute-force kernels walks two bounces (bit d: bounces d and d + 1).  Measured on the
-// Cornell box; pbrt_film_desc.flags can override it per call (PBRT_FILM_FUSE_PLAN).
+// Cornell box (0x1 while the two-bounce kernels ran at 6 - 7 waves per SIMD, every pair since they run
+// at 8); pbrt_film_desc.flags can override it per call (PBRT_FILM_FUSE_PLAN).
 #ifndef PBRT_DEFAULT_FUSE_PLAN
 #define PBRT_DEFAULT_FUSE_PLAN 0x15u
 #endif

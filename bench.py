@@ -63,14 +63,19 @@ CONFIGS = {
 
 
 def kernel_source_hash():
-    """sha256 over the kernel sources: ties profiles/pmc_traffic.json to the code it was measured on (the GPU box has
-    no .git to ask for HEAD)"""
+    """sha256 over the kernel sources and the build flags: ties profiles/pmc_traffic.json to the code it was measured on (the
+    GPU box has no .git to ask for HEAD).  Comments and blank lines are left out, so a reworded comment does not orphan a
+    measurement."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, PKG, "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
+        if name.endswith((".h", ".hip")) or name == "Makefile":
             h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+            for line in open(os.path.join(d, name), "r", errors="replace"):
+                code = line.split("//", 1)[0].strip() if name != "Makefile" else line.split("#", 1)[0].strip()
+                if code:
+                    h.update(code.encode())
+                    h.update(b"\n")
     return h.hexdigest()[:16]
 
 

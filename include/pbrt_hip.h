@@ -158,9 +158,12 @@ typedef struct pbrt_film_desc {
                                   for sample-sharded multi-GPU reduction */
 #define PBRT_FILM_NO_REPACK 2u /* diagnostic: BVH scenes, do not re-densify the live paths before bounces >= 2 \
                                   (same image either way) */
-#define PBRT_FILM_FUSE_PLAN_SET 0x80u /* bits 8..15 of flags hold the fuse plan: bit d set = the launch at depth d walks bounce d \
-                                        AND d + 1 of its paths in registers (brute-force kernels; same film either way). \
-                                        Unset: the library's default plan.  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce */
+#define PBRT_FILM_FUSE_PLAN_SET 0x80u /* bits 8..15 of flags hold the fuse plan: bit d set = the launch that walks bounce d goes on \
+                                        with bounce d + 1 of its paths in registers, up to 6 bounces per launch (brute-force \
+                                        kernels; same film whatever the plan).  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce, \
+                                        (0x15) = pairs, (0xff) = six bounces per launch.  Unset: the library chooses -- pairs for \
+                                        the first render of a scene, then the plan that follows from how many paths survived \
+                                        each bounce of the last one (it goes on while >= 45 % do) */
 #define PBRT_FILM_FUSE_PLAN(mask) (PBRT_FILM_FUSE_PLAN_SET | (((mask) & 0xffu) << 8))
 #define PBRT_FILM_WALK_SET 0x10000u /* bits 17..24 of flags hold the depth from which ONE launch walks every remaining bounce of a \
                                        pass (brute-force kernels: the workgroup that owns a segment carries its survivors on; \

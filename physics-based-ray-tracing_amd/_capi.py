@@ -40,7 +40,8 @@ def film_walk_from(depth: int) -> int:
 
 
 def film_fuse_plan(mask: int) -> int:
-    """flags value selecting which depths start a two-bounce launch (include/pbrt_hip.h PBRT_FILM_FUSE_PLAN)"""
+    """flags value: bit d of mask = the launch that walks bounce d goes on with bounce d + 1 in registers (include/pbrt_hip.h
+    PBRT_FILM_FUSE_PLAN; 0 = one launch per bounce, 0x15 = pairs, 0xff = six bounces per launch)"""
     return FILM_FUSE_PLAN_SET | ((int(mask) & 0xFF) << 8)
 
 US_MAX_ANGLES = 64

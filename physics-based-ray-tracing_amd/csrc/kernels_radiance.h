@@ -45,6 +45,7 @@ __host__ __device__ constexpr uint32_t rad_region_segs(int accel);
 __host__ __device__ constexpr uint32_t us_region_segs(int) { return REGION_SEGS_US; }
 #define N_STATE 15
 #define MAX_DEPTH_STATS 62
+#define MAX_CHAIN 6  // bounces one launch of the multi-bounce kernels walks at most (the per-bounce counts are packed 10 bits each)
 #define HIT_ROW0 (2 + MAX_DEPTH_STATS)  // k_bounce_pool: statistics rows HIT_ROW0 + d = rays of depth d that hit something
 
 // ACCEL_K_BRUTE      uniform primitive loop (scalar loads) + shading tables staged in LDS; every table <= 32 entries,
@@ -118,6 +119,7 @@ struct RadArgs {
     uint32_t cap;
     uint32_t n_paths;  // paths generated by the first bounce of this pass
     uint32_t depth, max_depth, rr_depth, seed;
+    uint32_t nb;  // bounces this launch walks (the multi-bounce variants k_bounce<.., 2>; 2 .. MAX_CHAIN)
     // key mode 0 (render): home -> (region pixel, local sample)
     uint32_t key_mode;
     uint32_t rx0, ry0, rw, npix_r, s_first, film_w, film_h;
@@ -380,8 +382,8 @@ DEV bool bounce_step(const RadArgs &a, const Tables &tb, const LdsScene &ls, Rsr
     return survive;
 }
 
-// NB: bounces walked by one launch (1 or 2; brute-force kernels only).  With NB = 2 a path that survives its first bounce
-// of the launch goes straight on in registers -- no state write, no compaction, no state read in between -- and the
+// NB = 2: the multi-bounce variant (brute-force kernels only): the launch walks a.nb (2 .. MAX_CHAIN) bounces.  A path that
+// survives a bounce of the launch goes straight on in registers -- no state write, no compaction, no state read in between -- and the
 // lanes whose paths ended idle through the second bounce (87 % / 83 % of the lanes stay busy at depths 0 / 2 of the
 // Cornell box, 20 % at depth 4 -- where the second bounce is the last one and only looks for emitters).  Same arithmetic
 // per bounce, same RNG keys: the film does not change.  Which depths start a two-bounce launch is the host's fuse plan
@@ -401,7 +403,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     __shared__ uint32_t wave_tot[2][SEG / 64];  // double-buffered across the chunk loop: one barrier per chunk
     __shared__ uint32_t wave_seg[2][SEG / 64];
     __shared__ uint32_t wave_shd[2][SEG / 64];
-    __shared__ uint32_t wave_mid[2][NB > 1 ? SEG / 64 : 1];  // NB = 2: paths that went on to the launch's second bounce
+    // multi-bounce launches: paths that went on to the launch's 2nd .. 6th bounce, 10 bits each (a workgroup has <= 512):
+    // bounces 2 - 4 in wave_mid, 5 - 6 in wave_mid_hi
+    __shared__ uint32_t wave_mid[2][NB > 1 ? SEG / 64 : 1], wave_mid_hi[2][NB > 1 ? SEG / 64 : 1];
 
     const uint32_t seg = xcd_swizzle(blockIdx.x, gridDim.x);  // region index
     const uint32_t tid = threadIdx.x;
@@ -458,7 +462,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
             wave_tot[0][tid >> 6] = 0;
             wave_seg[0][tid >> 6] = 0;
             wave_shd[0][tid >> 6] = 0;
-            if (NB > 1) wave_mid[0][tid >> 6] = 0;
+            if (NB > 1) {
+                wave_mid[0][tid >> 6] = 0;
+                wave_mid_hi[0][tid >> 6] = 0;
+            }
         }
         // s_endpgm behind the compiler's back keeps the kernel single-exit for the structurizer
         const uint32_t wave_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u;
@@ -480,7 +487,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
     const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
     uint32_t out_off = 0;      // survivors written so far (front of this region of the `out` state)
-    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0, mid_acc = 0;
+    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0, mid_acc = 0, mid_acc_hi = 0;
+    const uint32_t nb_run = NB > 1 ? min(a.nb, (uint32_t)MAX_CHAIN) : 1u;  // bounces this launch walks
     // the region's live paths sit compacted at its front: walk them SEG at a time; dead slots cost nothing
     for (uint32_t it0 = 0; it0 < (REGION > SEG ? cnt_in : 1u); it0 += CH) {  // single trip when REGION == SEG
     if (DYN) {  // take the next 64-path chunk of the region from the workgroup's queue
@@ -527,13 +535,17 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     if (ACCEL == ACCEL_K_BRUTE && !FIRST && !PERWAVE && it0 == 0) fill_tables_lds(a.sc, tab_lds, live_threads);
     if (alive && !FIRST) path_key<TILED>(a, home, &ka, &kb, &px, &py);
     bool live = alive;                        // the lane still carries a path
-    uint32_t nseg_w = 0, nshd_w = 0, nmid_w = 0;  // wave-uniform counts over the launch's bounces
+    uint32_t nseg_w = 0, nshd_w = 0, nmid_w = 0, nmid_hi_w = 0;  // wave-uniform counts over the launch's bounces
 #pragma unroll 1
-    for (uint32_t bounce = 0; bounce < (uint32_t)NB; ++bounce) {
+    for (uint32_t bounce = 0; bounce < nb_run; ++bounce) {
     const uint32_t depth = a.depth + bounce;
     if (NB > 1 && bounce > 0) {
         if (depth >= a.max_depth) break;      // uniform
-        nmid_w += (uint32_t)__popcll(__ballot(live));
+        const uint32_t n_on = (uint32_t)__popcll(__ballot(live));
+        if (bounce <= 3)
+            nmid_w += n_on << (10u * (bounce - 1u));
+        else
+            nmid_hi_w += n_on << (10u * (bounce - 4u));
         tmax = K_INF;
     }
     did_seg = false;
@@ -576,7 +588,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
         wave_tot[buf][wid] = (uint32_t)__popcll(bal);
         wave_seg[buf][wid] = nseg_w;
         wave_shd[buf][wid] = nshd_w;
-        if (NB > 1) wave_mid[buf][wid] = nmid_w;
+        if (NB > 1) {
+            wave_mid[buf][wid] = nmid_w;
+            wave_mid_hi[buf][wid] = nmid_hi_w;
+        }
     }
     __syncthreads();
     // exclusive scan over the waves' survivor counts on the scalar unit: one LDS read per lane, then
@@ -614,7 +629,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
         for (uint32_t w = 0; w < SEG / 64; ++w) {
             ns_acc += wave_seg[buf][w];
             nh_acc += wave_shd[buf][w];
-            if (NB > 1) mid_acc += wave_mid[buf][w];
+            if (NB > 1) {
+                mid_acc += wave_mid[buf][w];
+                mid_acc_hi += wave_mid_hi[buf][w];
+            }
         }
     }
     }  // chunk loop
@@ -640,7 +658,11 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
         row[0] += ns_acc;
         row[stride] += nh_acc;
         row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
-        if (NB > 1) row[(2 + min(a.depth + 1, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += mid_acc;
+        if (NB > 1)
+            for (uint32_t k = 1; k < nb_run; ++k) {
+                const uint32_t n_on = k <= 3 ? (mid_acc >> (10u * (k - 1u))) & 1023u : (mid_acc_hi >> (10u * (k - 4u))) & 1023u;
+                row[(2 + min(a.depth + k, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += n_on;
+            }
     }
 }
 

@@ -77,6 +77,9 @@ struct pbrt_scene {
     std::vector<void *> allocs;
     pbrt_material *d_mats = nullptr;
     uint32_t n_mats = 0;
+    // fuse plan learnt from the path survival of the last render of this scene (brute-force kernels; 0: none yet)
+    uint32_t plan_hint = 0;
+    bool plan_hint_valid = false;
 };
 
 #define HIPCHK(ctx, call)                                                                              \
@@ -439,19 +442,19 @@ static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t
             hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE_BIG, 1>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
     }
 }
-// nb: bounces this launch walks (2: the fused variants of the brute-force kernels, kernels_radiance.h)
+// nb: bounces this launch walks (>= 2: the multi-bounce variants of the brute-force kernels, kernels_radiance.h; a.nb = nb)
 template <bool FIRST>
 static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
-            if (nb == 2)
+            if (nb >= 2)
                 hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             else
                 hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
         case ACCEL_K_BRUTE_BIG:
-            if (nb == 2)
+            if (nb >= 2)
                 hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG, 2>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             else
                 hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
@@ -490,6 +493,28 @@ static int set_lds_attr(pbrt_scene *s) {
     return PBRT_OK;
 }
 
+// Fuse plan: bit d set = the launch that walks bounce d goes on with bounce d + 1 in registers (at most MAX_CHAIN bounces per
+// launch).  0 = one launch per bounce, 0x15 = pairs, all ones = as many bounces per launch as MAX_CHAIN allows.
+static uint32_t chain_len(uint32_t plan, uint32_t depth, uint32_t max_depth) {
+    uint32_t nb = 1;
+    while (nb < MAX_CHAIN && depth + nb < max_depth && depth + nb - 1 < 32 && ((plan >> (depth + nb - 1)) & 1u)) ++nb;
+    return nb;
+}
+// The plan that pays for a scene follows from how many paths survive each bounce: walking bounce d + 1 in the same launch saves
+// the state round trip of the survivors and costs the idle lanes of the others.  Measured (cbox, survival 0.87 / 0.77 / 0.83 /
+// 0.85 / 0.20: ONE launch for all six bounces 6.23 ms, triples 6.30, pairs 6.58; open scenes with survival 0.37 - 0.49 / 0.29 /
+// 0.33: pairs 2.11 / 4.52 ms, triples 2.11 / 4.84, one launch 2.47 / 5.70): go on while at least 45 % of the paths do; the last
+// bounce of a path only looks for emitters and is always taken along.  Any plan renders the same film.
+static uint32_t plan_from_survival(const unsigned long long *live, uint32_t max_depth) {
+    uint32_t plan = 0;
+    for (uint32_t d = 0; d + 1 < max_depth && d < 31; ++d) {
+        const bool last = d + 2 == max_depth;
+        if (live[d] == 0) break;
+        if (last || (double)live[d + 1] >= 0.45 * (double)live[d]) plan |= 1u << d;
+    }
+    return plan;
+}
+
 // Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
 // A launch that walks two bounces (fuse plan bit d) keeps its paths in registers between them: the survivors of bounce d
 // are neither written nor read back, only the survivors of bounce d + 1 are.
@@ -500,7 +525,7 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
                                  uint64_t *total, uint64_t *bounce) {
     uint64_t b = 0;
     for (uint32_t d = 0; d < nd;) {
-        const uint32_t nb = (d < 8 && ((fuse_plan >> d) & 1u) && d + 1 < max_depth && d + 1 < nd) ? 2u : 1u;
+        const uint32_t nb = std::min(chain_len(fuse_plan, d, max_depth), nd - d);
         uint64_t in = live[d], next = (d + nb < nd) ? live[d + nb] : 0;
         if (d > 0 && hits)
             b += in * 24 + hits[d] * (N_STATE * 4);
@@ -536,7 +561,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // 8.13 / 8.20 ms (fewer launch tails against cache residency of the ping-pong state)
     // round 2, fused first launch: 2 / 4 / 8 / 16 / 32 / 64 Mi -> 9.09 / 8.07 / 7.65 / 7.37 / 7.31 / 7.39 ms; BVH scenes keep 16 Mi
     const bool brute_scene = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
-    uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (32u << 20) : (16u << 20));
+    // round 2, chains of up to six bounces per launch (one launch per pass on the Cornell box): 2 / 4 / 8 / 16 / 32 / 64 Mi -> 7.85 / 7.01 /
+    // 6.72 / 6.56 / 6.49 / 6.43 ms
+    uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (64u << 20) : (16u << 20));
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
     s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
     NEED(c, npix_r * s_pass < 0xfffffc00ull);
@@ -581,6 +608,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     size_t n_ev = 0;
     hipEvent_t pass_e1 = nullptr;
     uint32_t passes = 0, launches = 0;
+    // the fuse plan of this call: the caller's, or the one learnt from the last render of this scene, or the library default
+    const bool brute_scene_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
+    const uint32_t call_plan = !brute_scene_k ? 0u
+                               : (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu)
+                               : (s->plan_hint_valid ? s->plan_hint : PBRT_DEFAULT_FUSE_PLAN);
     for (uint32_t s0 = 0; s0 < f->spp; s0 += s_pass, ++passes) {
         const uint32_t sc = std::min(s_pass, f->spp - s0);
         RadArgs a{};
@@ -617,7 +649,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
         const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
-        const uint32_t fuse_plan = (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN;
+        const uint32_t fuse_plan = call_plan;
         const uint32_t walk_from = (f->flags & PBRT_FILM_WALK_SET) ? ((f->flags >> 17) & 0xffu) : PBRT_DEFAULT_WALK_FROM;
         if (brute && (f->flags & PBRT_FILM_REGEN)) {
             // persistent waves with path regeneration (k_regen): one launch per pass, as many workgroups as the GPU holds at once
@@ -645,8 +677,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         for (uint32_t depth = 0; depth < f->max_depth;) {
             // bounces this launch walks: 2 at the depths of the fuse plan (brute-force kernels; the last bounce of a
             // path only looks for emitters, so it is never worth a launch slot of its own either)
-            const uint32_t nb = (brute && depth < 8 && ((fuse_plan >> depth) & 1u) && depth + 1 < f->max_depth) ? 2u : 1u;
+            const uint32_t nb = brute ? chain_len(fuse_plan, depth, f->max_depth) : 1u;
             a.depth = depth;
+            a.nb = nb;
             a.in = in;
             a.out = out;
             a.seg_in = sin;
@@ -775,7 +808,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint64_t tot, bb;
     for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
-    const uint32_t plan = !brute_k ? 0u : ((f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu) : PBRT_DEFAULT_FUSE_PLAN);
+    const uint32_t plan = call_plan;
+    if (brute_k && hstats[2] > 0) {  // remember what this scene's paths do for the next render of it
+        s->plan_hint = plan_from_survival(hstats + 2, (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS));
+        s->plan_hint_valid = true;
+    }
     radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth,
                          hit_pool ? hstats + HIT_ROW0 : nullptr, &tot, &bb);
     if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written

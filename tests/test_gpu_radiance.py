@@ -327,13 +327,18 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
     st0 = ctx.stats()
     ref, _ = oracle_render(ob, sc, 5, 6)
     assert np.array_equal(base, ref)
-    for plan in (0x1, 0x2, 0x4, 0x5, 0xA, 0x15, 0xFF):
+    for plan in (0x1, 0x2, 0x3, 0x4, 0x5, 0x7, 0xA, 0xE, 0x15, 0x1B, 0x1F, 0xFF):   # pairs, triples, chains of 4, 5 and 6 bounces
         img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(plan))
         st = ctx.stats()
         assert np.array_equal(img, base), hex(plan)
         assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
         assert st["bounce_launches"] <= st0["bounce_launches"] and st["bounce_model_bytes"] <= st0["bounce_model_bytes"]
-    assert np.array_equal(integ.render(sc, seed=5, spp=6), base)          # the library's default plan
+    md = integ.max_depth
+    img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(0xFF))
+    assert ctx.stats()["bounce_launches"] == ctx.stats()["passes"] * -(-md // 6)   # six bounces per launch
+    # the library's own choice: pairs for the first render of a scene, then the plan learnt from its path survival
+    assert np.array_equal(integ.render(sc, seed=5, spp=6), base) and np.array_equal(integ.render(sc, seed=5, spp=6), base)
+    assert list(ctx.stats()["live"]) == list(st0["live"])
     # k_walk: one launch walks every remaining bounce of a pass (PBRT_FILM_WALK_FROM), with and without a fused first trip
     for plan, walk in ((0x0, 0), (0x1, 0), (0x0, 1), (0x1, 2), (0x4, 2), (0x0, 3)):
         img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(plan) | capi.film_walk_from(walk))

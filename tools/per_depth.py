@@ -12,7 +12,8 @@ for r in rows:
         passes.append(cur); cur = []
     cur.append(r)
 passes.append(cur)
-n = max(len(p) for p in passes)
+lens = [len(p) for p in passes]
+n = max(set(lens), key=lens.count)   # the steady state (the set-up render of bench.py learns the launch plan)
 passes = [p for p in passes if len(p) == n]
 live = None
 bj = os.path.join(out, "bench_under_rocprof.json")

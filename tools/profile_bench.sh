@@ -15,5 +15,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_under_rocprof.json
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_fetch.log 2>&1 || { tail -20 $OUT/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py --steps 2 --warmup 0 --no-cpu-baseline "$@" > $OUT/pmc_write.log 2>&1 || { tail -20 $OUT/pmc_write.log; exit 1; }
+# 4. --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES : VALU-issue utilisation of the dominant kernel (a wave64 VALU instruction occupies its SIMD-32 for
+#    2 cycles; SQ_BUSY_CYCLES is summed over the 32 shader engines, 1024 SIMDs): busy = SQ_INSTS_VALU / (16 * SQ_BUSY_CYCLES)
+rocprofv3 --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_sq.log 2>&1 || { tail -20 $OUT/pmc_sq.log; exit 1; }
 python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

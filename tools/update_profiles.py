@@ -26,8 +26,13 @@ kernel = "k_us_bounce" if config.startswith("us_") else "k_bounce"
 def per_dispatch(sub, ctr):
     f = max(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)  # newest run
     tot, n = {}, {}
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != ctr or not any(k + "<" in r["Kernel_Name"] for k in (kernel, kernel + "_pool")):
+    rows = [r for r in csv.DictReader(open(f))
+            if r["Counter_Name"] == ctr and any(k + "<" in r["Kernel_Name"] for k in (kernel, kernel + "_pool"))]
+    # bench.py renders a radiance scene once at 2 spp while setting up (the library learns its launch plan from it): those small
+    # launches are not the workload -- keep the dispatches of the full-size grid only
+    gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+    for r in rows:
+        if int(r["Grid_Size"]) * 2 < gmax:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
@@ -42,8 +47,19 @@ path = os.path.join(dst, "pmc_traffic.json")
 allrec = json.load(open(path)) if os.path.exists(path) else {}
 if "k_bounce_hbm_bytes_per_launch" in allrec:   # round-1 layout: keep it under its own key
     allrec = {"r01_cbox": allrec}
+# VALU-issue utilisation of the dominant kernel family (4th pass of profile_bench.sh): a wave64 VALU instruction occupies its SIMD-32
+# for 2 cycles, SQ_BUSY_CYCLES is summed over the 32 shader engines of the 1024 SIMDs -> busy = SQ_INSTS_VALU / (16 * SQ_BUSY_CYCLES)
+valu_busy = None
+try:
+    iv, ni = per_dispatch("pmc_sq", "SQ_INSTS_VALU")
+    bc, nb = per_dispatch("pmc_sq", "SQ_BUSY_CYCLES")
+    tot_c = sum(bc[k] * nb[k] for k in bc)
+    valu_busy = round(sum(iv[k] * ni[k] for k in iv) / (16.0 * tot_c), 4) if tot_c else None
+except (ValueError, KeyError):
+    pass
 allrec[config] = {
     "kernel": kernel, "hbm_bytes_per_launch": round(num / max(sum(nf.values()), 1)), "kernel_source_sha16": kernel_source_hash(),
+    "valu_issue_busy": valu_busy,
     "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --config {config} --steps 2 "
            f"--warmup 0 --no-cpu-baseline` (tools/profile_bench.sh {tag}); bytes = ({fetch_factor:g}*FETCH_SIZE + {write_factor:g}*WRITE_SIZE)*1024 "
            f"per dispatch, averaged over the {kernel} dispatches; FETCH factor: tools/pmc_calibrate.sh on the kernel's own "

@@ -1,9 +1,12 @@
+"""Fuse plans on open scenes (few paths survive a bounce): kernel time of pairs / triples / 4 + 2 / one launch per pass on two of the
+random scenes of tests/test_gpu_random_scenes.py at 512^2 x 128 spp; same film for every plan."""
 import os, sys, tempfile, pathlib
-root = "/root/repo"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
 import numpy as np
 import pbrt_amd as mi
 from test_gpu_random_scenes import _random_scene
+capi = __import__("importlib").import_module("physics-based-ray-tracing_amd._capi")
 tmp = pathlib.Path(tempfile.mkdtemp())
 for seed, shape in ((1000, (3, 4, 0, 0)), (1001, (5, 10, 12, 0))):
     sc = _random_scene(mi, tmp, seed, *shape)
@@ -11,11 +14,10 @@ for seed, shape in ((1000, (3, 4, 0, 0)), (1001, (5, 10, 12, 0))):
     integ = sc.integrator(); integ.max_depth = 6
     ctx = mi.default_context()
     ref = None
-    for plan in ("222", "33", "42", "6"):
-        os.environ["PBRT_NB_PLAN"] = plan
+    for plan in ("15", "1b", "17", "1f"):   # pairs, triples, 4 + 2, one launch
         best = None
         for _ in range(4):
-            img = integ.render(sc, seed=0, spp=128, flags=0x20)
+            img = integ.render(sc, seed=0, spp=128, flags=capi.film_fuse_plan(int(plan, 16)))
             st = ctx.stats()
             if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
         if ref is None: ref = img

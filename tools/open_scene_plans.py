@@ -22,3 +22,9 @@ for seed, shape in ((1000, (3, 4, 0, 0)), (1001, (5, 10, 12, 0))):
             if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
         if ref is None: ref = img
         print(f"seed {seed} ({len(sc.flatten()['prims'])} prims) plan {plan}: kernel {best['kernel_ms']:.3f} ms  live/path {[round(x/best['samples'],3) for x in best['live'][:6]]} same {bool(np.array_equal(img, ref))}", flush=True)
+    best = None
+    for _ in range(4):
+        img = integ.render(sc, seed=0, spp=128)
+        st = ctx.stats()
+        if best is None or st["kernel_ms"] < best["kernel_ms"]: best = st
+    print(f"seed {seed} learnt plan: kernel {best['kernel_ms']:.3f} ms  launches per pass {best['bounce_launches'] // best['passes']} same {bool(np.array_equal(img, ref))}", flush=True)

@@ -635,7 +635,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.ry0 = ry0;
         a.rw = rw;
         a.npix_r = (uint32_t)npix_r;
-        a.tile_rows = (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) ? (rh & ~7u) : 0u;
+        a.tile_rows = rh & ~7u;
         a.div_npix = make_fastdiv(a.npix_r);
         a.div_rw = make_fastdiv(rw);
         for (uint32_t n : {0u, 1u, rw - 1, rw, rw + 1, a.npix_r - 1, a.npix_r, a.npix_r + 1, cap - 1, cap, 0xffffffffu}) {

@@ -194,11 +194,6 @@ def main():
                                       host_collective=bool(args.rehearse_on_one_gpu and world > 1))
         return buf
 
-    if radiance:
-        # part of the set-up, like the upload: the library picks the launch structure of a brute-force scene from the path survival
-        # of the scene's LAST render (pairs of bounces for the first one), so the scene is rendered once at 2 spp before any step --
-        # warm-up and timed steps then all run the same, learnt plan (any plan renders the same film)
-        scene.integrator().render(scene, seed=seed, spp=2)
     for _ in range(warmup):
         step()
     for k in acc:

@@ -161,9 +161,9 @@ typedef struct pbrt_film_desc {
 #define PBRT_FILM_FUSE_PLAN_SET 0x80u /* bits 8..15 of flags hold the fuse plan: bit d set = the launch that walks bounce d goes on \
                                         with bounce d + 1 of its paths in registers, up to 6 bounces per launch (brute-force \
                                         kernels; same film whatever the plan).  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce, \
-                                        (0x15) = pairs, (0xff) = six bounces per launch.  Unset: the library chooses -- pairs for \
-                                        the first render of a scene, then the plan that follows from how many paths survived \
-                                        each bounce of the last one (it goes on while >= 45 % do) */
+                                        (0x15) = pairs, (0xff) = six bounces per launch.  Unset: the library chooses from how many \
+                                        paths survive each bounce (it goes on while >= 45 % do) -- measured on a 2-spp probe \
+                                        pass at the start of the first render of a scene, afterwards on the scene's last render */
 #define PBRT_FILM_FUSE_PLAN(mask) (PBRT_FILM_FUSE_PLAN_SET | (((mask) & 0xffu) << 8))
 #define PBRT_FILM_WALK_SET 0x10000u /* bits 17..24 of flags hold the depth from which ONE launch walks every remaining bounce of a \
                                        pass (brute-force kernels: the workgroup that owns a segment carries its survivors on; \

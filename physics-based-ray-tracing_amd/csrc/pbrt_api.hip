@@ -610,11 +610,18 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t passes = 0, launches = 0;
     // the fuse plan of this call: the caller's, or the one learnt from the last render of this scene, or the library default
     const bool brute_scene_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
-    const uint32_t call_plan = !brute_scene_k ? 0u
-                               : (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu)
-                               : (s->plan_hint_valid ? s->plan_hint : PBRT_DEFAULT_FUSE_PLAN);
-    for (uint32_t s0 = 0; s0 < f->spp; s0 += s_pass, ++passes) {
-        const uint32_t sc = std::min(s_pass, f->spp - s0);
+    uint32_t call_plan = !brute_scene_k ? 0u
+                         : (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu)
+                         : (s->plan_hint_valid ? s->plan_hint : PBRT_DEFAULT_FUSE_PLAN);
+    // First render of a brute-force scene with the plan left to the library: the first PROBE_SPP samples are a pass of their own,
+    // their path survival is read back (one synchronisation, ~30 us) and decides the plan of all the other passes.  The film does
+    // not depend on how the samples are split into passes, nor on the plan.
+    constexpr uint32_t PROBE_SPP = 2;
+    const bool probe = brute_scene_k && !s->plan_hint_valid && f->spp >= 8 * PROBE_SPP && s_pass >= PROBE_SPP &&
+                       !(f->flags & (PBRT_FILM_FUSE_PLAN_SET | PBRT_FILM_WALK_SET | PBRT_FILM_REGEN));
+    uint32_t s_step = s_pass;  // samples of a regular pass
+    for (uint32_t s0 = 0; s0 < f->spp; ++passes) {
+        const uint32_t sc = (probe && passes == 0) ? PROBE_SPP : std::min(s_step, f->spp - s0);
         RadArgs a{};
         a.sc = s->ds;
         if ((f->flags & PBRT_FILM_NO_OCCLUDER_PRUNING) && a.sc.occ_prims) {  // diagnostic: shadow segments walk every primitive
@@ -775,6 +782,19 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 hipLaunchKernelGGL((k_film_accum_tiled<8, PBRT_FILTER_GAUSSIAN>), g8, dim3(8, 8), 0, st, fa);
         }
         HIPCHK(c, hipGetLastError());
+        s0 += sc;
+        if (probe && passes == 0) {  // learn the plan from the probe pass
+            unsigned long long hp[2 + MAX_DEPTH_STATS];
+            hipLaunchKernelGGL(k_reduce_stats, dim3(stat_rows, REDUCE_SLICES), dim3(256), 0, st, segstats, n_rows, (size_t)n_rows, dstats);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(hp, dstats, (size_t)stat_rows * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + 2 * MAX_DEPTH_STATS) * 8, st));  // the final reduction adds every row again
+            for (uint32_t d = stat_rows; d < 2 + MAX_DEPTH_STATS; ++d) hp[d] = 0;
+            call_plan = plan_from_survival(hp + 2, (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS));
+            const uint32_t rem = f->spp - s0;
+            s_step = div_up(rem, div_up(rem, s_pass));  // equal passes for what is left
+        }
     }
     hipLaunchKernelGGL(k_film_resolve, dim3(div_up(film_px, 256)), dim3(256), 0, st, acc, (float *)d_out, (uint32_t)film_px,
                        (uint32_t)((f->flags & PBRT_FILM_RAW_ACCUM) ? 1 : 0));

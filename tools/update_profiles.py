@@ -28,8 +28,8 @@ def per_dispatch(sub, ctr):
     tot, n = {}, {}
     rows = [r for r in csv.DictReader(open(f))
             if r["Counter_Name"] == ctr and any(k + "<" in r["Kernel_Name"] for k in (kernel, kernel + "_pool"))]
-    # bench.py renders a radiance scene once at 2 spp while setting up (the library learns its launch plan from it): those small
-    # launches are not the workload -- keep the dispatches of the full-size grid only
+    # the first render of a brute-force scene starts with a 2-spp probe pass (the library learns its launch plan from it): those
+    # small launches are not the workload -- keep the dispatches of the full-size grid only
     gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
     for r in rows:
         if int(r["Grid_Size"]) * 2 < gmax:

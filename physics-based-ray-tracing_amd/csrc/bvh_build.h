@@ -225,56 +225,152 @@ inline void build_bvh(const pbrt_prim *prims, uint32_t n, HostBvh *out) {
     b.build(0, 0, n, 0);
 }
 
-// ---- inner-node form for the stackless device traversal (DevNode in device_scene.h) ---------------
-struct HostInner {
-    float lo0[3];
-    uint32_t c0;
-    float hi0[3];
-    uint32_t c1;
-    float lo1[3];
-    uint32_t parent;
-    float hi1[3];
-    uint32_t pad;
+// ---- BVH4 for the device: the SAH BVH2 above collapsed to four children per node, child boxes on an 8-bit grid --------------
+// A node holds the lower corner of its (padded) box, one power-of-two grid step per axis, and for every child six grid
+// coordinates rounded OUTWARD (a child's grid box contains its padded float box), so one 64-byte read decides four descents and
+// the tree has about a third of the BVH2's nodes.  Children keep the left-to-right order of the BVH2 (the subtree below the
+// split plane first), `axis` = the split axis of the collapsed BVH2 node: a ray with a negative direction component on it
+// visits the children in descending order.  Leaves reference ranges of the 40-byte leaf records (HostLeafPrim).
+struct HostNode4 {
+    float org[3];
+    uint32_t exps;      // biased exponents of the grid step: x | y << 8 | z << 16; bits 24..25: split axis
+    uint32_t child[4];  // inner: node index; leaf: 0x80000000 | count << 27 | first; empty slot: 0x80000000
+    uint32_t qlo[3];    // qlo[axis]: byte k = lower plane of child k
+    uint32_t qhi[3];    // qhi[axis]: byte k = upper plane of child k
+    uint32_t pad[2];
+};
+struct HostLeafPrim {  // what a primitive test reads: v0 / e1 / e2 (sphere: centre, radius) and type << 28 | caller's index
+    float g[9];
+    uint32_t meta;
+};
+
+struct HostBvh4 {
+    std::vector<HostNode4> nodes;
+    uint32_t depth = 0;  // levels of inner nodes (root = 1)
 };
 
 namespace bvh_detail {
-inline uint32_t emit_inner(const HostBvh &b, uint32_t old_idx, uint32_t parent, std::vector<HostInner> *out) {
-    const HostNode &n = b.nodes[old_idx];
-    if (!(n.b & 0x80000000u)) return 0x80000000u | ((n.b & 15u) << 27) | (n.a & 0x07ffffffu);  // leaf reference
-    const uint32_t idx = (uint32_t)out->size();
-    out->push_back(HostInner{});
-    const HostNode &l = b.nodes[n.a], &r = b.nodes[n.a + 1];
-    HostInner in{};
-    for (int k = 0; k < 3; ++k) {
-        in.lo0[k] = l.lo[k];
-        in.hi0[k] = l.hi[k];
-        in.lo1[k] = r.lo[k];
-        in.hi1[k] = r.hi[k];
+inline float box_area(const HostNode &n) {
+    const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+inline bool is_leaf2(const HostNode &n) { return !(n.b & 0x80000000u); }
+
+inline uint32_t emit4(const HostBvh &b, uint32_t idx2, uint32_t level, HostBvh4 *out) {
+    out->depth = std::max(out->depth, level);
+    const HostNode &n = b.nodes[idx2];
+    std::vector<uint32_t> kids = {n.a, n.a + 1};
+    while (kids.size() < 4) {  // open the inner child with the largest box, in place (keeps the left-to-right order)
+        int best = -1;
+        float ba = -1.0f;
+        for (size_t k = 0; k < kids.size(); ++k) {
+            const HostNode &c = b.nodes[kids[k]];
+            if (is_leaf2(c)) continue;
+            const float a = box_area(c);
+            if (a > ba) {
+                ba = a;
+                best = (int)k;
+            }
+        }
+        if (best < 0) break;
+        const uint32_t l = b.nodes[kids[best]].a;
+        kids[best] = l;
+        kids.insert(kids.begin() + best + 1, l + 1);
     }
-    in.parent = parent;
-    in.c0 = emit_inner(b, n.a, idx, out);
-    in.c1 = emit_inner(b, n.a + 1, idx, out);
-    (*out)[idx] = in;
-    return idx;
+    const uint32_t my = (uint32_t)out->nodes.size();
+    out->nodes.push_back(HostNode4{});
+    HostNode4 N{};
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t k : kids)
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = std::min(lo[c], (double)b.nodes[k].lo[c]);
+            hi[c] = std::max(hi[c], (double)b.nodes[k].hi[c]);
+        }
+    int e[3];
+    for (int c = 0; c < 3; ++c) {
+        N.org[c] = (float)lo[c];  // min of floats: exact
+        const double ext = hi[c] - lo[c];
+        int ex = -126;
+        if (ext > 0.0) {
+            int fe;
+            std::frexp(ext / 255.0, &fe);  // ext / 255 = m * 2^fe, m in [0.5, 1)  =>  2^fe > ext / 255
+            ex = std::max(fe, -126);
+        }
+        while (std::ldexp(255.0, ex) < ext) ++ex;
+        e[c] = ex;
+    }
+    for (int c = 0; c < 3; ++c) {
+        uint32_t wl = 0, wh = 0;
+        for (size_t k = 0; k < 4; ++k) {
+            uint32_t ql = 255, qh = 0;  // empty slot: inverted, never hit
+            if (k < kids.size()) {
+                const double step = std::ldexp(1.0, e[c]);
+                const double fl = std::floor(((double)b.nodes[kids[k]].lo[c] - lo[c]) / step);
+                const double ch = std::ceil(((double)b.nodes[kids[k]].hi[c] - lo[c]) / step);
+                ql = (uint32_t)std::min(255.0, std::max(0.0, fl));
+                qh = (uint32_t)std::min(255.0, std::max(0.0, ch));
+                // the grid box must contain the float box (exact in f64: lo + q * 2^e)
+                while (ql > 0 && lo[c] + ql * step > (double)b.nodes[kids[k]].lo[c]) --ql;
+                while (qh < 255 && lo[c] + qh * step < (double)b.nodes[kids[k]].hi[c]) ++qh;
+            }
+            wl |= ql << (8 * k);
+            wh |= qh << (8 * k);
+        }
+        N.qlo[c] = wl;
+        N.qhi[c] = wh;
+    }
+    N.exps = (uint32_t)(e[0] + 127) | ((uint32_t)(e[1] + 127) << 8) | ((uint32_t)(e[2] + 127) << 16) | ((n.b & 3u) << 24);
+    for (size_t k = 0; k < 4; ++k) {
+        if (k >= kids.size()) {
+            N.child[k] = 0x80000000u;
+            continue;
+        }
+        const HostNode &c = b.nodes[kids[k]];
+        if (is_leaf2(c))
+            N.child[k] = 0x80000000u | ((c.b & 15u) << 27) | (c.a & 0x07ffffffu);
+        else
+            N.child[k] = emit4(b, kids[k], level + 1, out);
+    }
+    out->nodes[my] = N;
+    return my;
 }
 }  // namespace bvh_detail
 
-inline void to_inner_nodes(const HostBvh &b, std::vector<HostInner> *out) {
-    out->clear();
+inline void to_bvh4(const HostBvh &b, HostBvh4 *out) {
+    out->nodes.clear();
+    out->depth = 0;
     const HostNode &root = b.nodes[0];
-    if (!(root.b & 0x80000000u)) {  // the whole scene is one leaf: wrap it
-        HostInner in{};
-        for (int k = 0; k < 3; ++k) {
-            in.lo0[k] = root.lo[k];
-            in.hi0[k] = root.hi[k];
-            in.lo1[k] = INFINITY;
-            in.hi1[k] = -INFINITY;
+    if (bvh_detail::is_leaf2(root)) {  // the whole scene is one leaf: a node with one child
+        HostNode4 N{};
+        for (int c = 0; c < 3; ++c) {
+            N.org[c] = root.lo[c];
+            const double ext = (double)root.hi[c] - (double)root.lo[c];
+            int ex = -126;
+            while (std::ldexp(255.0, ex) < ext) ++ex;
+            const double step = std::ldexp(1.0, ex);
+            uint32_t qh = (uint32_t)std::min(255.0, std::ceil(ext / step));
+            while (qh < 255 && (double)root.lo[c] + qh * step < (double)root.hi[c]) ++qh;
+            N.qlo[c] = 0xffffff00u;  // children 1..3 empty: lo 255
+            N.qhi[c] = qh;           // ... hi 0
+            N.exps |= (uint32_t)(ex + 127) << (8 * c);
         }
-        in.c0 = 0x80000000u | ((root.b & 15u) << 27) | (root.a & 0x07ffffffu);
-        in.c1 = 0x80000000u;  // empty leaf
-        in.parent = 0;
-        out->push_back(in);
+        N.child[0] = 0x80000000u | ((root.b & 15u) << 27) | (root.a & 0x07ffffffu);
+        N.child[1] = N.child[2] = N.child[3] = 0x80000000u;
+        out->nodes.push_back(N);
+        out->depth = 1;
         return;
     }
-    bvh_detail::emit_inner(b, 0, 0, out);
+    bvh_detail::emit4(b, 0, 1, out);
+}
+
+// the leaf records in leaf order (order[slot] = caller's index)
+inline void make_leaf_prims(const pbrt_prim *prims, const std::vector<uint32_t> &order, std::vector<HostLeafPrim> *out) {
+    out->resize(order.size());
+    for (size_t s = 0; s < order.size(); ++s) {
+        const pbrt_prim &P = prims[order[s]];
+        HostLeafPrim L{};
+        for (int k = 0; k < 9; ++k) L.g[k] = P.g[k];  // cone: the record is read from the full table (meta holds the index)
+        L.meta = (P.type << 28) | (order[s] & 0x0fffffffu);
+        (*out)[s] = L;
+    }
 }

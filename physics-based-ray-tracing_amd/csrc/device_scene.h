@@ -5,27 +5,31 @@
 #include "../../include/pbrt_hip.h"
 #include "device_math.h"
 
-// BVH2 inner node, 64 bytes: the boxes of BOTH children plus their references, so one node read
-// decides both descents.  Child reference c: bit 31 set = leaf, bits 27..30 = primitive count (0..15),
-// bits 0..26 = first primitive (leaf order); bit 31 clear = index of an inner node.
-// `parent` = index of the parent inner node (root: 0).  Traversal keeps no stack: a 64-bit trail of
-// "far sibling still pending" bits plus the parent links (bit-trail traversal, Afra & Szirmay-Kalos).
-struct DevNode {
-    float lo0[3];
-    uint32_t c0;
-    float hi0[3];
-    uint32_t c1;
-    float lo1[3];
-    uint32_t parent;
-    float hi1[3];
-    uint32_t pad;
+// BVH4 inner node, 64 bytes (bvh_build.h HostNode4): lower corner of the node's box, a power-of-two grid step per axis and
+// the boxes of FOUR children on that 8-bit grid, rounded outward -- one node read decides four descents.
+// Child reference c: bit 31 set = leaf, bits 27..30 = primitive count (0..15; 0 = empty slot), bits 0..26 = first leaf record;
+// bit 31 clear = index of an inner node.  Traversal keeps a short per-lane stack of child references in LDS (BvhStack).
+struct DevNode4 {
+    float org[3];
+    uint32_t exps;      // biased exponents of the grid step: x | y << 8 | z << 16; bits 24..25: split axis of the collapsed BVH2 node
+    uint32_t child[4];
+    uint32_t qlo[3];    // qlo[axis]: byte k = lower plane of child k
+    uint32_t qhi[3];
+    uint32_t pad[2];
+};
+// Leaf record, 40 bytes: what a primitive TEST reads (v0 / e1 / e2; sphere: centre + radius), type << 28 | caller's index.
+// Normal, material and emitter of the primitive that was hit come from the full 64-byte table (prims_by_id) afterwards.
+struct DevLeafPrim {
+    float g[9];
+    uint32_t meta;
 };
 #define BVH_LEAF 0x80000000u
+#define BVH_SENT 0xffffffffu  // bottom of the traversal stack
 
 struct DevScene {
-    const pbrt_prim *prims;  // BRUTE: caller order.  BVH: leaf order
-    const uint32_t *prim_ids;  // BVH: leaf-order slot -> caller's primitive index (nullptr for BRUTE)
-    const DevNode *nodes;
+    const pbrt_prim *prims;  // caller order (== prims_by_id); Hit::slot indexes it
+    const DevLeafPrim *lprims;  // BVH: the leaf records in leaf order
+    const DevNode4 *nodes;
     const pbrt_material *mats;
     const pbrt_emitter *emitters;
     const uint32_t *light_prims;  // caller's primitive indices
@@ -42,7 +46,7 @@ struct DevScene {
     const struct PairItem *pair_items;  // ACCEL_K_BRUTE: sc.prims as pairs of planar primitives (brute_closest_pairs)
     uint32_t n_pair_items;
 #endif
-    // optional: the vertex normals of mesh primitives, [n_prims][9], indexed like `prims` (by Hit::slot); nullptr: face normals
+    // optional: the vertex normals of mesh primitives, [n_prims][9], caller order (indexed by Hit::slot); nullptr: face normals
     const float *vnormals;
     uint32_t n_prims, n_nodes, n_emitters, n_mats, n_light_prims;
 };
@@ -101,56 +105,59 @@ DEV bool cone_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *f
 // One primitive against one ray; identical arithmetic to the oracle's prim_hit (Mitsuba
 // Mesh::ray_intersect_triangle / Sphere / Rectangle reached via scene.ray_intersect,
 // CustomIntegrator.py:309).  The barycentric test runs on det-scaled values so that the division
-// is only executed for accepted candidates.
+// is only executed for accepted candidates.  The per-type forms take the geometry as plain vectors: the 64-byte
+// records of the brute-force loop and the 40-byte leaf records of the BVH go through the same arithmetic.
+DEV bool sphere_hit(V3 c, float r, V3 o, V3 d, float tmax, float *t) {
+    V3 f = o - c;
+    float bp = -dot(f, d);
+    V3 perp = madd(d, bp, f);
+    float disc = fma_(r, r, -dot(perp, perp));
+    if (!(disc >= 0.0f)) return false;
+    float sq = sqrtf(disc);
+    float q = bp + copysignf(sq, bp);
+    float cc = fma_(-r, r, dot(f, f));
+    float t0 = cc / q, t1 = q;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    if (!(tn <= tmax && tf >= 0.0f)) return false;
+    if (tn < 0.0f && tf > tmax) return false;
+    *t = tn < 0.0f ? tf : tn;
+    return true;
+}
+DEV bool planar_hit(bool triangle, V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tmax, float *t, float *u, float *v) {
+    V3 pvec = cross(d, e2);
+    float det = dot(e1, pvec);
+    V3 tvec = o - v0;
+    V3 qvec = cross(tvec, e1);
+    float us = dot(tvec, pvec), vs = dot(d, qvec), ts = dot(e2, qvec);
+    if (det < 0.0f) {
+        det = -det;
+        us = -us;
+        vs = -vs;
+        ts = -ts;
+    }
+    bool ok = det > 0.0f && us >= 0.0f && vs >= 0.0f && ts >= 0.0f;
+    if (triangle)
+        ok = ok && (us + vs <= det);
+    else
+        ok = ok && (us <= det) && (vs <= det);
+    if (!ok) return false;
+    float inv = 1.0f / det;
+    float tt = ts * inv;
+    if (!(tt <= tmax)) return false;
+    *t = tt;
+    *u = us * inv;
+    *v = vs * inv;
+    return true;
+}
 DEV bool prim_hit(const pbrt_prim &P, V3 o, V3 d, float tmax, float *t, float *u, float *v) {
     const uint32_t type = P.type;
     if (type == PBRT_PRIM_SPHERE) {
-        V3 c = g3(P, 0);
-        float r = P.g[3];
-        V3 f = o - c;
-        float bp = -dot(f, d);
-        V3 perp = madd(d, bp, f);
-        float disc = fma_(r, r, -dot(perp, perp));
-        if (!(disc >= 0.0f)) return false;
-        float sq = sqrtf(disc);
-        float q = bp + copysignf(sq, bp);
-        float cc = fma_(-r, r, dot(f, f));
-        float t0 = cc / q, t1 = q;
-        float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-        if (!(tn <= tmax && tf >= 0.0f)) return false;
-        if (tn < 0.0f && tf > tmax) return false;
-        *t = tn < 0.0f ? tf : tn;
         *u = 0.0f;
         *v = 0.0f;
-        return true;
+        return sphere_hit(g3(P, 0), P.g[3], o, d, tmax, t);
     }
-    if (type == PBRT_PRIM_TRIANGLE || type == PBRT_PRIM_PARALLELOGRAM) {
-        V3 v0 = g3(P, 0), e1 = g3(P, 3), e2 = g3(P, 6);
-        V3 pvec = cross(d, e2);
-        float det = dot(e1, pvec);
-        V3 tvec = o - v0;
-        V3 qvec = cross(tvec, e1);
-        float us = dot(tvec, pvec), vs = dot(d, qvec), ts = dot(e2, qvec);
-        if (det < 0.0f) {
-            det = -det;
-            us = -us;
-            vs = -vs;
-            ts = -ts;
-        }
-        bool ok = det > 0.0f && us >= 0.0f && vs >= 0.0f && ts >= 0.0f;
-        if (type == PBRT_PRIM_TRIANGLE)
-            ok = ok && (us + vs <= det);
-        else
-            ok = ok && (us <= det) && (vs <= det);
-        if (!ok) return false;
-        float inv = 1.0f / det;
-        float tt = ts * inv;
-        if (!(tt <= tmax)) return false;
-        *t = tt;
-        *u = us * inv;
-        *v = vs * inv;
-        return true;
-    }
+    if (type == PBRT_PRIM_TRIANGLE || type == PBRT_PRIM_PARALLELOGRAM)
+        return planar_hit(type == PBRT_PRIM_TRIANGLE, g3(P, 0), g3(P, 3), g3(P, 6), o, d, tmax, t, u, v);
     if (type == PBRT_PRIM_CONE) {
         *v = 0.0f;
         return cone_hit(P, o, d, tmax, t, u);
@@ -362,19 +369,18 @@ DEV bool brute_closest_pairs(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h)
 }
 #endif  // PBRT_BRUTE_PAIRS
 
-// ---- BVH2 traversal without a stack; NodeP / PrimP / IdP are global or LDS pointers -------------
-// Box tests are conservative (boxes are padded at build time, reciprocal directions are approximate);
-// only prim_hit decides, and ties in t go to the lowest primitive id, so the result does not depend on
-// the tree or on the visiting order.
+// ---- BVH4 traversal; NodeP / PrimP are global or LDS pointers ------------------------------------
+// Box tests are conservative (boxes are padded at build time and rounded outward onto the node's grid, reciprocal
+// directions are approximate); only the primitive tests decide, and ties in t go to the lowest primitive id, so the result
+// does not depend on the tree or on the visiting order.
 //
-// Slab form t = plane * (1/d) - o * (1/d): one fma per plane instead of a subtraction and a product (12 VALU less per
-// node, a fifth of a traversal step).  Its rounding error is that of moving the plane by <= 2^-23 * (|plane| + |o|),
-// two orders of magnitude inside the builder's padding (2e-5 * scene size, bvh_build.h), so a box the exact test
-// accepts is never culled.  A zero direction component would make both products infinite (inf - inf = NaN hides
-// the slab, but -inf - inf = -inf culls a box the ray is inside of), so components below 1e-18 are replaced by
-// +-1e-18 for the box tests only: all products stay finite and the sign of (plane - o) survives for every plane
-// further than the padding from the ray.
-#ifndef PBRT_BOX_SUBMUL  // diagnostic builds: the (plane - o) * (1/d) form
+// Slab form: a child plane sits at org + q * step (q = 0..255), so  t = (org + q step - o) / d = q * A + B  with
+// A = step * (1/d) and B = org * (1/d) - o * (1/d) per node and axis: one v_cvt_f32_ubyte + one fma per plane.  The
+// rounding error is that of moving the plane by a few 2^-23 * (|plane| + |o|), two orders of magnitude inside the
+// builder's padding (2e-5 * scene size, bvh_build.h), so a box the exact test accepts is never culled.  A zero direction
+// component would make the products infinite (inf - inf = NaN hides the slab, but -inf - inf = -inf culls a box the ray is
+// inside of), so components below 1e-18 are replaced by +-1e-18 for the box tests only: all products stay finite and the
+// sign of (plane - o) survives for every plane further than the padding from the ray.
 struct BoxRay {
     V3 oi, inv;  // o / d, 1 / d
 };
@@ -385,237 +391,163 @@ DEV BoxRay make_box_ray(V3 o, V3 d) {
     const V3 inv = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z)};
     return {{o.x * inv.x, o.y * inv.y, o.z * inv.z}, inv};
 }
-DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const BoxRay &r, float best, float *tn_) {
-    float tx0 = fma_(lox, r.inv.x, -r.oi.x), tx1 = fma_(hix, r.inv.x, -r.oi.x);
-    float ty0 = fma_(loy, r.inv.y, -r.oi.y), ty1 = fma_(hiy, r.inv.y, -r.oi.y);
-    float tz0 = fma_(loz, r.inv.z, -r.oi.z), tz1 = fma_(hiz, r.inv.z, -r.oi.z);
-#else
-struct BoxRay {
-    V3 o, inv;
+
+// Per-lane traversal stack: the newest entry lives in a register (`tos`), rows 0 .. n_rows - 1 of an LDS array
+// [row][thread] hold the next ones (row n_rows is a scratch row for the branch-free push), anything deeper goes to a
+// private array (scratch memory; the host checks that 3 * depth + 1 <= BVH_STK_MAX).  A pop hands out `tos` and requests
+// the next entry right away, so its LDS latency is covered by the node test that follows.
+#define BVH_STK_OVF 40
+#define BVH_STK_MAX (BVH_STK_OVF + 2)  // guaranteed capacity whatever n_rows is (>= 2 rows are always there)
+struct BvhStack {
+    uint32_t *col;     // this thread's column: entry of row r at col[r * stride]; nullptr: brute-force kernels
+    uint32_t stride;   // threads of the workgroup
+    uint32_t n_rows;   // rows that hold entries (>= 2); one more row exists behind them
 };
-DEV BoxRay make_box_ray(V3 o, V3 d) {
-    return {o, {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z)}};
+struct BvhCursor {
+    uint32_t cur, tos, sp;
+    uint32_t ovf[BVH_STK_OVF];
+};
+DEV void bvh_push(const BvhStack &st, BvhCursor &c, bool on, uint32_t ref) {
+    if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // wave-uniform
+    st.col[min(c.sp, st.n_rows) * st.stride] = c.tos;   // lanes that do not push write above their top / into the scratch row
+    if (on && c.sp >= st.n_rows) c.ovf[min(c.sp - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)] = c.tos;
+    c.sp += on ? 1u : 0u;
+    c.tos = on ? ref : c.tos;
 }
-DEV bool box_test(float lox, float loy, float loz, float hix, float hiy, float hiz, const BoxRay &r, float best, float *tn_) {
-    float tx0 = (lox - r.o.x) * r.inv.x, tx1 = (hix - r.o.x) * r.inv.x;
-    float ty0 = (loy - r.o.y) * r.inv.y, ty1 = (hiy - r.o.y) * r.inv.y;
-    float tz0 = (loz - r.o.z) * r.inv.z, tz1 = (hiz - r.o.z) * r.inv.z;
-#endif
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), best));
-    *tn_ = tn;
-    return tn <= tf;
+DEV uint32_t bvh_pop(const BvhStack &st, BvhCursor &c) {
+    const uint32_t r = c.tos;
+    const bool has = c.sp > 0;
+    const uint32_t sp1 = has ? c.sp - 1u : 0u;
+    uint32_t nxt = st.col[min(sp1, st.n_rows - 1u) * st.stride];
+    if (has && sp1 >= st.n_rows) nxt = c.ovf[min(sp1 - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)];
+    c.tos = has ? nxt : BVH_SENT;
+    c.sp = sp1;
+    return r;
 }
 
-// Diagnostic (-DPBRT_BVH_RING=n, default off): n deferred far children are kept in registers (node | level << 24,
-// newest first); a pop takes the newest one and shifts the trail by the level difference instead of climbing the
-// parent links one dependent LDS read per level; the ring forgets its oldest entry on overflow and the climb finds
-// that sibling.  Same visiting order, same result -- and no gain: ring scene 24.0 ms without, 27.2 / 25.6 / 25.0 /
-// 25.3 ms with 2 / 3 / 4 / 6 entries (the register moves cost what the climbs cost); 896-triangle cone 9.15 -> 9.0 ms.
-#ifndef PBRT_BVH_RING
-#define PBRT_BVH_RING 0
-#endif
-// Two-phase ("while-while") traversal: a lane walks inner nodes until it holds a leaf to test or has finished, and the
-// primitives of the held leaves are tested when EVERY lane of the wave has got that far.  The primitive test is the long
-// part of a step (60 VALU per primitive against 40 for the two boxes of a node) and in the one-loop form below it ran in
-// almost every trip for the few lanes that happened to stand at a leaf (later bounces of the ring: 19 % of the lanes active
-// per VALU instruction).  Holding a leaf delays the update of `best`, so a lane may visit a node more than it would have:
-// still conservative, and the result does not depend on the visiting order (ties in t go to the lowest primitive id).
+// One inner node: the four child boxes against the ray, the nearest hit child becomes the cursor, the others are pushed
+// (in index order, reversed for rays that run against the node's split axis: about front to back), no hit pops.
+template <typename NodeP>
+DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, const BoxRay &r, float best) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    const auto *np = nodes + c.cur;
+    const u32x4 w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
+    const u32x4 w1 = *reinterpret_cast<const u32x4 *>(&np->child[0]);
+    const u32x4 w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
+    const u32x2 w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
+    const uint32_t exps = w0.w;
+    const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
+                Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
+    const float Bx = fma_(__uint_as_float(w0.x), r.inv.x, -r.oi.x), By = fma_(__uint_as_float(w0.y), r.inv.y, -r.oi.y),
+                Bz = fma_(__uint_as_float(w0.z), r.inv.z, -r.oi.z);
+    const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
+    const uint32_t qnx = nx ? w2.w : w2.x, qfx = nx ? w2.x : w2.w;   // planes the ray enters / leaves through
+    const uint32_t qny = ny ? w3.x : w2.y, qfy = ny ? w2.y : w3.x;
+    const uint32_t qnz = nz ? w3.y : w2.z, qfz = nz ? w2.z : w3.y;
+    uint32_t key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tnx = fma_((float)((qnx >> (8 * k)) & 0xffu), Ax, Bx), tfx = fma_((float)((qfx >> (8 * k)) & 0xffu), Ax, Bx);
+        const float tny = fma_((float)((qny >> (8 * k)) & 0xffu), Ay, By), tfy = fma_((float)((qfy >> (8 * k)) & 0xffu), Ay, By);
+        const float tnz = fma_((float)((qnz >> (8 * k)) & 0xffu), Az, Bz), tfz = fma_((float)((qfz >> (8 * k)) & 0xffu), Az, Bz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
+        key[k] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : 0xffffffffu;  // tn >= 0: ordered like the floats
+    }
+    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+    const uint32_t near = kmin & 3u;
+    const bool h0 = key[0] != 0xffffffffu && near != 0u, h1 = key[1] != 0xffffffffu && near != 1u,
+               h2 = key[2] != 0xffffffffu && near != 2u, h3 = key[3] != 0xffffffffu && near != 3u;
+    // push the others so that the one met first along the split axis is popped first
+    const uint32_t axis = (exps >> 24) & 3u;
+    const bool rev = axis == 0u ? nx : (axis == 1u ? ny : nz);
+    bvh_push(st, c, rev ? h0 : h3, rev ? w1.x : w1.w);
+    bvh_push(st, c, rev ? h1 : h2, rev ? w1.y : w1.z);
+    bvh_push(st, c, rev ? h2 : h1, rev ? w1.z : w1.y);
+    bvh_push(st, c, rev ? h3 : h0, rev ? w1.w : w1.x);
+    if (kmin == 0xffffffffu) {
+        c.cur = bvh_pop(st, c);
+    } else {
+        c.cur = near == 0u ? w1.x : (near == 1u ? w1.y : (near == 2u ? w1.z : w1.w));
+    }
+}
+
+// One leaf record against the ray (`full`: the 64-byte table, read for cones only)
+template <typename PrimP>
+DEV bool lprim_hit(PrimP lprims, uint32_t slot, const pbrt_prim *full, V3 o, V3 d, float tmax, float *t, float *u, float *v,
+                   uint32_t *id) {
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    const u32x2 *q = reinterpret_cast<const u32x2 *>(&lprims[slot]);
+    const u32x2 a = q[0], b = q[1], cc = q[2], dd = q[3], e = q[4];
+    const uint32_t meta = e.y, type = meta >> 28;
+    *id = meta & 0x0fffffffu;
+    const V3 v0 = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x)};
+    if (type == PBRT_PRIM_SPHERE) {
+        *u = 0.0f;
+        *v = 0.0f;
+        return sphere_hit(v0, __uint_as_float(b.y), o, d, tmax, t);
+    }
+    if (type == PBRT_PRIM_CONE) {
+        *v = 0.0f;
+        return cone_hit(full[*id], o, d, tmax, t, u);
+    }
+    const V3 e1 = {__uint_as_float(b.y), __uint_as_float(cc.x), __uint_as_float(cc.y)};
+    const V3 e2 = {__uint_as_float(dd.x), __uint_as_float(dd.y), __uint_as_float(e.x)};
+    return planar_hit(type == PBRT_PRIM_TRIANGLE, v0, e1, e2, o, d, tmax, t, u, v);
+}
+
+// Two-phase ("while-while") traversal: a lane walks inner nodes until it holds a leaf or has finished, and the primitives of
+// the held leaves are tested when EVERY lane of the wave has got that far (the primitive test is the long part of a step).
+// Holding a leaf delays the update of `best`, so a lane may visit a node more than it would have: still conservative.
 #ifdef PBRT_BVH_PROBE  // diagnostic builds: how many of a wave's traversal trips does a lane use?  (tools/bvh_probe.py)
 __device__ unsigned long long g_bvh_probe[8];  // closest hit: wave trips x 64, lane trips (node walk), same for primitive tests; any hit: +4
 #define BVH_PROBE_FIRST_LANE() \
     (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u)
 #endif
-#ifndef PBRT_BVH_ONE_LOOP
-template <bool ANY, typename NodeP, typename PrimP, typename IdP>
-DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
-#ifdef PBRT_BVH_PROBE
-    uint32_t pn1 = 0, pw1 = 0, pn2 = 0, pw2 = 0;
-    struct ProbeFlush {
-        uint32_t &n1, &w1, &n2, &w2;
-        __device__ ~ProbeFlush() {
-            const int b = ANY ? 4 : 0;
-            atomicAdd(&g_bvh_probe[b + 0], (unsigned long long)w1);
-            atomicAdd(&g_bvh_probe[b + 1], (unsigned long long)n1);
-            atomicAdd(&g_bvh_probe[b + 2], (unsigned long long)w2);
-            atomicAdd(&g_bvh_probe[b + 3], (unsigned long long)n2);
-        }
-    } probe_flush{pn1, pw1, pn2, pw2};
-#endif
+template <bool ANY, typename NodeP, typename PrimP>
+DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const BvhStack &st, V3 o, V3 d, float tmax, Hit *h) {
     const BoxRay br = make_box_ray(o, d);
-    uint32_t node = 0;
-    unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
-    bool found = false, done = false;
-    float best = tmax;
-    uint32_t leaf_a = 0, leaf_b = 0;  // held leaf references (BVH_LEAF set, so never 0)
-    for (;;) {
-        while (!done && leaf_a == 0) {
-#ifdef PBRT_BVH_PROBE
-            ++pn1;
-            if (BVH_PROBE_FIRST_LANE()) pw1 += 64;
-#endif
-            const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
-            float t0, t1;
-            const bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0],
-                                     nodes[node].hi0[1], nodes[node].hi0[2], br, best, &t0);
-            const bool h1 = box_test(nodes[node].lo1[0], nodes[node].lo1[1], nodes[node].lo1[2], nodes[node].hi1[0],
-                                     nodes[node].hi1[1], nodes[node].hi1[2], br, best, &t1);
-            const bool l0 = h0 && (c0 & BVH_LEAF), l1 = h1 && (c1 & BVH_LEAF);
-            leaf_a = l0 ? c0 : (l1 ? c1 : 0u);
-            leaf_b = (l0 && l1) ? c1 : 0u;
-            const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
-            if (i0 || i1) {
-                const bool both = i0 && i1;
-                const bool near0 = both ? (t0 <= t1) : i0;
-                trail = (trail << 1) | (both ? 1ull : 0ull);
-                node = near0 ? c0 : c1;
-                continue;
-            }
-            // pop: climb until a level with a pending sibling
-            while ((trail & 1ull) == 0ull) {
-                if (trail == 0ull) {
-                    done = true;
-                    break;
-                }
-                trail >>= 1;
-                node = nodes[node].parent;
-            }
-            if (!done) {
-                const uint32_t p = nodes[node].parent;
-                node = (nodes[p].c0 == node) ? nodes[p].c1 : nodes[p].c0;
-                trail ^= 1ull;
-            }
-        }
-        if (leaf_a == 0) break;  // this lane has finished (the wave leaves the loop when every lane has)
-#pragma unroll 1
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t c = side ? leaf_b : leaf_a;
-            if (c == 0) break;
-            const uint32_t first = c & 0x07ffffffu, count = (c >> 27) & 15u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const uint32_t slot = first + k;
-                float t, u, v;
-#ifdef PBRT_BVH_PROBE
-                ++pn2;
-                if (BVH_PROBE_FIRST_LANE()) pw2 += 64;
-#endif
-                if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
-                    if (ANY) return true;
-                    const uint32_t id = prim_ids[slot];
-                    if (!found || t < best || (t == best && id < h->prim)) {
-                        best = t;
-                        h->t = t;
-                        h->u = u;
-                        h->v = v;
-                        h->prim = id;
-                        h->slot = slot;
-                        found = true;
-                    }
-                }
-            }
-        }
-        leaf_a = 0;
-        leaf_b = 0;
-    }
-    return found;
-}
-#else
-template <bool ANY, typename NodeP, typename PrimP, typename IdP>
-DEV bool bvh_intersect(NodeP nodes, PrimP prims, IdP prim_ids, V3 o, V3 d, float tmax, Hit *h) {
-    const BoxRay br = make_box_ray(o, d);
-    uint32_t node = 0;
-    unsigned long long trail = 0;  // bit k: the sibling at depth k from the current node is still pending
+    BvhCursor c;
+    c.cur = 0;
+    c.tos = BVH_SENT;
+    c.sp = 0;
     bool found = false;
     float best = tmax;
-#if PBRT_BVH_RING > 0
-    uint32_t ring[PBRT_BVH_RING];  // fully unrolled accesses: stays in VGPRs
-    uint32_t ring_n = 0, lvl = 0;  // valid entries, depth of `node` below the root
-#endif
     for (;;) {
-        const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
-        float t0, t1;
-        bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0], nodes[node].hi0[1],
-                           nodes[node].hi0[2], br, best, &t0);
-        bool h1 = box_test(nodes[node].lo1[0], nodes[node].lo1[1], nodes[node].lo1[2], nodes[node].hi1[0], nodes[node].hi1[1],
-                           nodes[node].hi1[2], br, best, &t1);
-        // leaves are tested on the spot
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            const uint32_t c = side ? c1 : c0;
-            const bool hit = side ? h1 : h0;
-            if (hit && (c & BVH_LEAF)) {
-                const uint32_t first = c & 0x07ffffffu, count = (c >> 27) & 15u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t slot = first + k;
-                    float t, u, v;
-                    if (prim_hit(prims[slot], o, d, best, &t, &u, &v)) {
-                        if (ANY) return true;
-                        const uint32_t id = prim_ids[slot];
-                        if (!found || t < best || (t == best && id < h->prim)) {
-                            best = t;
-                            h->t = t;
-                            h->u = u;
-                            h->v = v;
-                            h->prim = id;
-                            h->slot = slot;
-                            found = true;
-                        }
-                    }
+        while ((int32_t)c.cur >= 0) {
+#ifdef PBRT_BVH_PROBE
+            atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 1], 1ull);
+            if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 0], 64ull);
+#endif
+            bvh_visit(nodes, st, c, br, best);
+        }
+        if (c.cur == BVH_SENT) break;  // this lane has finished (the wave leaves the loop when every lane has)
+        const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
+        for (uint32_t k = 0; k < count; ++k) {
+            float t, u, v;
+            uint32_t id;
+#ifdef PBRT_BVH_PROBE
+            atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 3], 1ull);
+            if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 2], 64ull);
+#endif
+            if (lprim_hit(lprims, first + k, full, o, d, best, &t, &u, &v, &id)) {
+                if (ANY) return true;
+                if (!found || t < best || (t == best && id < h->prim)) {
+                    best = t;
+                    h->t = t;
+                    h->u = u;
+                    h->v = v;
+                    h->prim = id;
+                    h->slot = id;
+                    found = true;
                 }
             }
         }
-        const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
-        if (i0 || i1) {
-            const bool both = i0 && i1;
-            const bool near0 = both ? (t0 <= t1) : i0;
-            trail = (trail << 1) | (both ? 1ull : 0ull);
-#if PBRT_BVH_RING > 0
-            ++lvl;
-            if (both) {  // defer the far child
-#pragma unroll
-                for (int k = PBRT_BVH_RING - 1; k > 0; --k) ring[k] = ring[k - 1];
-                ring[0] = (near0 ? c1 : c0) | (lvl << 24);
-                ring_n = min(ring_n + 1u, (uint32_t)PBRT_BVH_RING);
-            }
-#endif
-            node = near0 ? c0 : c1;
-            continue;
-        }
-        // pop
-#if PBRT_BVH_RING > 0
-        if (ring_n > 0) {  // the newest deferred child is the pending sibling nearest above (pushes and pops are LIFO)
-            const uint32_t e = ring[0];
-#pragma unroll
-            for (int k = 0; k + 1 < PBRT_BVH_RING; ++k) ring[k] = ring[k + 1];
-            --ring_n;
-            const uint32_t l = e >> 24;
-            trail = (trail >> (lvl - l)) ^ 1ull;
-            lvl = l;
-            node = e & 0x00ffffffu;
-            continue;
-        }
-#endif
-        // climb until a level with a pending sibling
-        bool done = false;
-        while ((trail & 1ull) == 0ull) {
-            if (trail == 0ull) {
-                done = true;
-                break;
-            }
-            trail >>= 1;
-            node = nodes[node].parent;
-#if PBRT_BVH_RING > 0
-            --lvl;
-#endif
-        }
-        if (done) break;
-        const uint32_t p = nodes[node].parent;
-        node = (nodes[p].c0 == node) ? nodes[p].c1 : nodes[p].c0;
-        trail ^= 1ull;
+        c.cur = bvh_pop(st, c);
     }
     return found;
 }
-#endif  // PBRT_BVH_ONE_LOOP
 
 // ---- surface interaction ------------------------------------------------------------------------
 struct SI {

@@ -204,12 +204,21 @@ DEV void path_key(const RadArgs &a, uint32_t home, uint32_t *ka, uint32_t *kb, u
     }
 }
 
-// LDS image of the BVH scene: [nodes | prims | prim_ids]
+// LDS image of the BVH scene: [nodes | leaf records], and the workgroup's traversal stacks (device_scene.h BvhStack)
 struct LdsScene {
-    const DevNode *nodes;
-    const pbrt_prim *prims;
-    const uint32_t *ids;
+    const DevNode4 *nodes;
+    const DevLeafPrim *lprims;
+    BvhStack stk;
 };
+#ifndef BVH_STK_ROWS
+#define BVH_STK_ROWS 4  // LDS rows of the traversal stacks of the fused kernels (+ 1 scratch row); deeper entries go to scratch memory
+#endif
+#define BVH_STK_DW(threads) ((BVH_STK_ROWS + 1) * (threads))
+DEV BvhStack make_bvh_stack(uint32_t *lds, uint32_t threads) { return {lds + threadIdx.x, threads, BVH_STK_ROWS}; }
+// static LDS of a kernel that may walk a BVH: its traversal stacks (one dword for the brute-force variants)
+#define BVH_STACK_LDS(ACCEL, THREADS) \
+    __shared__ uint32_t bvh_stk_lds[((ACCEL) == ACCEL_K_BVH_GLOBAL || (ACCEL) == ACCEL_K_BVH_LDS) ? BVH_STK_DW(THREADS) : 1]
+#define NO_LDS_SCENE {nullptr, nullptr, {nullptr, 0u, 0u}}
 
 // SEGMENT: the ray is a segment between two points of the scene (next-event shadow ray): brute-force
 // scenes then only walk the primitives that can occlude such a segment (DevScene::occ_prims).
@@ -220,8 +229,8 @@ DEV bool scene_intersect(const DevScene &sc, const LdsScene &ls, V3 o, V3 d, flo
 #endif
     if (ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG)
         return brute_intersect<ANY, SEGMENT, ACCEL != ACCEL_K_BRUTE>(sc, o, d, tmax, h);
-    if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(sc.nodes, sc.prims, sc.prim_ids, o, d, tmax, h);
-    return bvh_intersect<ANY>(ls.nodes, ls.prims, ls.ids, o, d, tmax, h);
+    if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(sc.nodes, sc.lprims, sc.prims, ls.stk, o, d, tmax, h);
+    return bvh_intersect<ANY>(ls.nodes, ls.lprims, sc.prims, ls.stk, o, d, tmax, h);
 }
 
 // ACCEL_K_BRUTE: copy the (<= 32-entry) shading tables into LDS; layout [prims | mats | emitters | light_prims | light_cdf]
@@ -258,25 +267,21 @@ DEV Tables stage_tables_lds(const DevScene &sc, uint32_t *lds) {
 template <int ACCEL>
 DEV Tables make_tables(const DevScene &sc, const LdsScene &ls, uint32_t *tab_lds) {
     if (ACCEL == ACCEL_K_BRUTE) return stage_tables_lds(sc, tab_lds);
-    Tables tb = global_tables(sc);
-    if (ACCEL == ACCEL_K_BVH_LDS) tb.prims_by_slot = ls.prims;
-    return tb;
+    return global_tables(sc);  // BVH: Hit::slot is the caller's index, the hit primitive's full record comes from global memory
 }
 
-// stage nodes + prims + ids into LDS (cooperative, 16 B per lane per step)
+// stage nodes + leaf records into LDS (cooperative, 16 B per lane per step; both arrays are multiples of 8 bytes, the
+// image is padded to 16)
 DEV void stage_scene_lds(const DevScene &sc, uint32_t *lds, LdsScene *ls) {
-    const uint32_t node_dw = sc.n_nodes * 16, prim_dw = sc.n_prims * 16, id_dw = sc.n_prims;
+    const uint32_t node_dw = sc.n_nodes * 16, prim_dw = sc.n_prims * 10;
     const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
-    const uint4 *src_p = reinterpret_cast<const uint4 *>(sc.prims);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
     for (uint32_t i = threadIdx.x; i < node_dw / 4; i += blockDim.x) dst[i] = src_n[i];
-    uint4 *dst_p = dst + node_dw / 4;
-    for (uint32_t i = threadIdx.x; i < prim_dw / 4; i += blockDim.x) dst_p[i] = src_p[i];
-    uint32_t *dst_i = lds + node_dw + prim_dw;
-    for (uint32_t i = threadIdx.x; i < id_dw; i += blockDim.x) dst_i[i] = sc.prim_ids[i];
-    ls->nodes = reinterpret_cast<const DevNode *>(lds);
-    ls->prims = reinterpret_cast<const pbrt_prim *>(lds + node_dw);
-    ls->ids = lds + node_dw + prim_dw;
+    const uint2 *src_p = reinterpret_cast<const uint2 *>(sc.lprims);
+    uint2 *dst_p = reinterpret_cast<uint2 *>(lds + node_dw);
+    for (uint32_t i = threadIdx.x; i < prim_dw / 2; i += blockDim.x) dst_p[i] = src_p[i];
+    ls->nodes = reinterpret_cast<const DevNode4 *>(lds);
+    ls->lprims = reinterpret_cast<const DevLeafPrim *>(lds + node_dw);
     __syncthreads();
 }
 
@@ -478,7 +483,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
                      ".Llive_%=:" ::"s"(wave_first), "s"(cnt_in) : "scc", "memory");
     }
     const uint32_t live_threads = early_exit ? (min(cnt_in, SEG) + 63u) & ~63u : SEG;  // waves still present
-    LdsScene ls = {nullptr, nullptr, nullptr};
+    BVH_STACK_LDS(ACCEL, SEG);
+    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, SEG)};
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
     if (DYN && ACCEL != ACCEL_K_BVH_LDS) __syncthreads();               // publishes the queue words
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
@@ -668,276 +674,6 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     }
 }
 
-// ---- k_bounce_pool: BVH scenes, bounces >= 1 -- a stream of closest-hit queries, shading in full waves ------------------
-// After the first bounce the rays of a mesh scene are incoherent and most of them leave it (TestRing: 77 % of the rays of
-// bounce 1 hit nothing): in k_bounce a wave walked the tree until its LAST lane had finished (tools/bvh_probe.py: 32 % of
-// the lanes used by the node walk of bounce 1, 18 % by the primitive tests), and the shading, the emitter sample and its
-// shadow ray of the paths that did hit ran in the few lanes that were left.  Here the two are taken apart:
-//   * the closest-hit queries of a region are a STREAM: a lane whose ray has finished takes the next path of the region's
-//     queue (origin and direction are all it needs) and joins the walk of the others at the next turn of the loop; a ray
-//     that hit nothing ends its path on the spot, a ray that hit something leaves (state slot, hit) on the wave's own
-//     stack in LDS;
-//   * once the stack holds a wave's worth (or nothing else is left) 64 entries are popped, their full state is loaded and
-//     the rest of the bounce runs with every lane busy, while the unfinished rays of the stream wait in their registers.
-// Same arithmetic per path, same keys, any order: the film does not change.  Slot reservation for the survivors and the
-// statistics as in k_bounce's chunk-queue form.
-#define POOL_CAP 112u  // entries per wave: idle lanes take new rays while <= POOL_CAP - 64 hits wait (every ray in flight may add one),
-                       // shading starts above that; 112 is what fits beside the 120 KB image of the TestRing in the 160 KB of a CU
-#define POOL_BYTES (SEG_BVH / 64 * POOL_CAP * 5u * 4u)
-#ifndef POOL_WALK_MIN
-#define POOL_WALK_MIN 16u  // ring 1024^2 x 64: 21.68 ms without the early stop, 21.11 / 21.31 / 22.15 at 16 / 32 / 48 (k_bounce: 22.85)
-#endif
-template <int ACCEL>
-__global__ __launch_bounds__(SEG_BVH, SEG_BVH / 256) void k_bounce_pool(const RadArgs a) {
-    static_assert(ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS, "hit pool: BVH kernels");
-    constexpr uint32_t SEG = SEG_BVH, W = SEG / 64, REGION = rad_region_segs(ACCEL) * SEG;
-    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
-    __shared__ uint32_t q_in, q_out, q_done;
-    __shared__ uint32_t pool_slot[W][POOL_CAP], pool_prim[W][POOL_CAP];  // state slot of the path, leaf-order slot of the primitive
-    __shared__ float pool_t[W][POOL_CAP], pool_u[W][POOL_CAP], pool_v[W][POOL_CAP];
-    const uint32_t seg = xcd_swizzle(blockIdx.x, gridDim.x);
-    const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-    const uint32_t base = seg * REGION;
-    if (tid == 0) {
-        q_in = 0;
-        q_out = 0;
-        q_done = 0;
-    }
-    uint32_t cnt_in = a.seg_in[seg];
-    if (cnt_in == 0) {  // uniform across the workgroup
-        if (tid == 0) a.seg_out[seg] = 0;
-        return;
-    }
-    cnt_in = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_in);
-    LdsScene ls = {nullptr, nullptr, nullptr};
-    if (ACCEL == ACCEL_K_BVH_LDS)
-        stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
-    else
-        __syncthreads();  // publishes the queue words
-    __shared__ uint32_t tab_none[1];
-    const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_none);
-    const DevNode *nodes = ACCEL == ACCEL_K_BVH_LDS ? ls.nodes : a.sc.nodes;
-    const pbrt_prim *prims = ACCEL == ACCEL_K_BVH_LDS ? ls.prims : a.sc.prims;
-    const uint32_t *prim_ids = ACCEL == ACCEL_K_BVH_LDS ? ls.ids : a.sc.prim_ids;
-    const uint32_t cap = a.cap;
-    const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
-    const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
-    constexpr uint32_t row = STATE_ROW_BYTES;
-    const uint32_t depth = a.depth;
-    uint32_t pool_n = 0;  // wave-uniform
-    bool queue_empty = false;
-    uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0;
-    // the lane's query of the stream (bvh_intersect's two-phase walk, one leaf batch per turn of the loop)
-    bool busy = false, walk_done = false, found = false;
-    uint32_t q_slot = 0, node = 0, leaf_a = 0, leaf_b = 0, best_prim = 0, best_slot = 0;
-    unsigned long long trail = 0;
-    float best = K_INF, best_u = 0.0f, best_v = 0.0f;
-    V3 qo = {0, 0, 0}, qd = {0, 0, 1};
-    BoxRay br = make_box_ray(qo, qd);
-    for (;;) {
-        // ---- retire the queries that have finished
-        if (busy && walk_done && leaf_a == 0) {
-            if (!found) {  // the path left the scene: its radiance is final
-                const uint32_t v4 = state_voff(q_slot);
-                typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-                const u32x4 rec = {__float_as_uint(bld(r_in, v4 + 9 * row, 0)), __float_as_uint(bld(r_in, v4 + 10 * row, 0)),
-                                   __float_as_uint(bld(r_in, v4 + 11 * row, 0)), 0u};
-                const uint32_t home = __float_as_uint(bld(r_in, v4 + 14 * row, 0));
-                __builtin_amdgcn_raw_buffer_store_b128(rec, r_L, home * 16u, 0, 0);
-            }
-            busy = false;
-        } else {
-            found = busy ? found : false;  // (idle lanes push nothing)
-        }
-        {
-            const bool push = !busy && found;
-            const unsigned long long bh = __ballot(push);
-            if (push) {
-                const uint32_t e = pool_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
-                pool_slot[wid][e] = q_slot;
-                pool_prim[wid][e] = best_slot;
-                pool_t[wid][e] = best;
-                pool_u[wid][e] = best_u;
-                pool_v[wid][e] = best_v;
-                found = false;
-            }
-            const uint32_t nhit = (uint32_t)__popcll(bh);
-            pool_n += nhit;
-            ns_acc += nhit;
-        }
-        // ---- idle lanes take the next paths of the region while the stack has room for every ray in flight
-        if (!queue_empty && pool_n <= POOL_CAP - 64u) {
-            const unsigned long long bi = __ballot(!busy);
-            if (bi) {
-                const uint32_t n_idle = (uint32_t)__popcll(bi);
-                uint32_t nxt = 0;
-                if (lane == 0) nxt = atomicAdd(&q_in, n_idle);
-                const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)nxt);
-                if (it0 + n_idle >= cnt_in) queue_empty = true;
-                const uint32_t it = it0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bi >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bi, 0u));
-                if (!busy && it < cnt_in) {
-                    q_slot = base + it;
-                    const uint32_t v4 = state_voff(q_slot);
-                    qo = {bld(r_in, v4 + 0 * row, 0), bld(r_in, v4 + 1 * row, 0), bld(r_in, v4 + 2 * row, 0)};
-                    qd = {bld(r_in, v4 + 3 * row, 0), bld(r_in, v4 + 4 * row, 0), bld(r_in, v4 + 5 * row, 0)};
-                    br = make_box_ray(qo, qd);
-                    busy = true;
-                    walk_done = false;
-                    found = false;
-                    node = 0;
-                    trail = 0;
-                    best = K_INF;
-                    leaf_a = 0;
-                    leaf_b = 0;
-                }
-                live_acc += it0 < cnt_in ? min(n_idle, cnt_in - it0) : 0u;
-            }
-        }
-        const bool any_busy = __ballot(busy) != 0;
-        // ---- shade a wave's worth of hits (or what is left when nothing else is)
-        if (pool_n > POOL_CAP - 64u || (!any_busy && pool_n > 0)) {
-            const uint32_t take = min(pool_n, 64u);
-            const bool has = lane < take;
-            bool survive = false, did_seg = false, did_shadow = false;
-            V3 o = {0, 0, 0}, d = {0, 0, 1}, thr = {0, 0, 0}, L = {0, 0, 0};
-            float eta = 1.0f, prev_pdf = -1.0f;
-            uint32_t home = 0;
-            if (has) {
-                const uint32_t e = pool_n - take + lane;
-                const uint32_t slot = pool_slot[wid][e];
-                Hit h;
-                h.slot = pool_prim[wid][e];
-                h.prim = prim_ids[h.slot];
-                h.t = pool_t[wid][e];
-                h.u = pool_u[wid][e];
-                h.v = pool_v[wid][e];
-                const uint32_t v4 = state_voff(slot);
-                o = {bld(r_in, v4 + 0 * row, 0), bld(r_in, v4 + 1 * row, 0), bld(r_in, v4 + 2 * row, 0)};
-                d = {bld(r_in, v4 + 3 * row, 0), bld(r_in, v4 + 4 * row, 0), bld(r_in, v4 + 5 * row, 0)};
-                thr = {bld(r_in, v4 + 6 * row, 0), bld(r_in, v4 + 7 * row, 0), bld(r_in, v4 + 8 * row, 0)};
-                L = {bld(r_in, v4 + 9 * row, 0), bld(r_in, v4 + 10 * row, 0), bld(r_in, v4 + 11 * row, 0)};
-                eta = bld(r_in, v4 + 12 * row, 0);
-                prev_pdf = bld(r_in, v4 + 13 * row, 0);
-                home = __float_as_uint(bld(r_in, v4 + 14 * row, 0));
-                uint32_t ka, kb, px, py;
-                path_key<true>(a, home, &ka, &kb, &px, &py);
-                survive = bounce_step<ACCEL, true>(a, tb, ls, r_L, depth, ka, kb, home, K_INF, o, d, thr, L, eta, prev_pdf, did_seg,
-                                                   did_shadow, &h);
-            }
-            pool_n -= take;
-            const unsigned long long bal = __ballot(survive);
-            const uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            const uint32_t cnt_w = (uint32_t)__popcll(bal);
-            uint32_t got = 0;
-            if (lane == 0 && cnt_w) got = atomicAdd(&q_out, cnt_w);
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            nh_acc += (uint32_t)__popcll(__ballot(did_shadow));
-            if (survive) {
-                const uint32_t v4 = state_voff(base + off + prefix);
-                bst(r_out, v4 + 0 * row, 0, o.x);
-                bst(r_out, v4 + 1 * row, 0, o.y);
-                bst(r_out, v4 + 2 * row, 0, o.z);
-                bst(r_out, v4 + 3 * row, 0, d.x);
-                bst(r_out, v4 + 4 * row, 0, d.y);
-                bst(r_out, v4 + 5 * row, 0, d.z);
-                bst(r_out, v4 + 6 * row, 0, thr.x);
-                bst(r_out, v4 + 7 * row, 0, thr.y);
-                bst(r_out, v4 + 8 * row, 0, thr.z);
-                bst(r_out, v4 + 9 * row, 0, L.x);
-                bst(r_out, v4 + 10 * row, 0, L.y);
-                bst(r_out, v4 + 11 * row, 0, L.z);
-                bst(r_out, v4 + 12 * row, 0, eta);
-                bst(r_out, v4 + 13 * row, 0, prev_pdf);
-                bst(r_out, v4 + 14 * row, 0, __uint_as_float(home));
-            }
-            continue;
-        }
-        if (!any_busy) break;  // nothing in flight, nothing to shade; the queue is empty or every lane would have a ray
-        // ---- one turn of the walk: inner nodes until every busy lane holds a leaf or has finished, then the held leaves
-        // (while new rays can be had, the walk stops as soon as fewer than POOL_WALK_MIN lanes are still in it: the others have
-        // finished or hold a leaf, and waiting for the deepest walker would idle them.  A lane that stops early keeps its place
-        // in the tree.  Every turn still makes progress: a leaf is tested, a ray is fetched, or -- once the queue is empty --
-        // the walk runs to its end.)
-        const bool can_refill = !queue_empty && pool_n <= POOL_CAP - 64u;  // wave-uniform
-        while (busy && !walk_done && leaf_a == 0) {
-            if (can_refill && (uint32_t)__popcll(__ballot(true)) < POOL_WALK_MIN) break;
-#ifdef PBRT_BVH_PROBE
-            atomicAdd(&g_bvh_probe[1], 1ull);
-            if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[0], 64ull);
-#endif
-            const uint32_t c0 = nodes[node].c0, c1 = nodes[node].c1;
-            float t0, t1;
-            const bool h0 = box_test(nodes[node].lo0[0], nodes[node].lo0[1], nodes[node].lo0[2], nodes[node].hi0[0],
-                                     nodes[node].hi0[1], nodes[node].hi0[2], br, best, &t0);
-            const bool h1 = box_test(nodes[node].lo1[0], nodes[node].lo1[1], nodes[node].lo1[2], nodes[node].hi1[0],
-                                     nodes[node].hi1[1], nodes[node].hi1[2], br, best, &t1);
-            const bool l0 = h0 && (c0 & BVH_LEAF), l1 = h1 && (c1 & BVH_LEAF);
-            leaf_a = l0 ? c0 : (l1 ? c1 : 0u);
-            leaf_b = (l0 && l1) ? c1 : 0u;
-            const bool i0 = h0 && !(c0 & BVH_LEAF), i1 = h1 && !(c1 & BVH_LEAF);
-            if (i0 || i1) {
-                const bool both = i0 && i1;
-                const bool near0 = both ? (t0 <= t1) : i0;
-                trail = (trail << 1) | (both ? 1ull : 0ull);
-                node = near0 ? c0 : c1;
-                continue;
-            }
-            while ((trail & 1ull) == 0ull) {  // pop: climb until a level with a pending sibling
-                if (trail == 0ull) {
-                    walk_done = true;
-                    break;
-                }
-                trail >>= 1;
-                node = nodes[node].parent;
-            }
-            if (!walk_done) {
-                const uint32_t p = nodes[node].parent;
-                node = (nodes[p].c0 == node) ? nodes[p].c1 : nodes[p].c0;
-                trail ^= 1ull;
-            }
-        }
-        if (busy && leaf_a != 0) {
-#pragma unroll 1
-            for (int side = 0; side < 2; ++side) {
-                const uint32_t c = side ? leaf_b : leaf_a;
-                if (c == 0) break;
-                const uint32_t first = c & 0x07ffffffu, count = (c >> 27) & 15u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t ps = first + k;
-                    float t, u, v;
-#ifdef PBRT_BVH_PROBE
-                    atomicAdd(&g_bvh_probe[3], 1ull);
-                    if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[2], 64ull);
-#endif
-                    if (prim_hit(prims[ps], qo, qd, best, &t, &u, &v)) {
-                        const uint32_t id = prim_ids[ps];
-                        if (!found || t < best || (t == best && id < best_prim)) {
-                            best = t;
-                            best_u = u;
-                            best_v = v;
-                            best_prim = id;
-                            best_slot = ps;
-                            found = true;
-                        }
-                    }
-                }
-            }
-            leaf_a = 0;
-            leaf_b = 0;
-        }
-    }
-    if (lane == 0) {
-        unsigned long long *srow = a.stats + (seg * W + wid);  // per-wave statistics rows
-        const size_t stride = a.stat_stride;
-        srow[0] += ns_acc;
-        srow[stride] += nh_acc;
-        srow[(2 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += live_acc;
-        srow[(HIT_ROW0 + min(depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += ns_acc;  // hits of this depth (byte model)
-        // the last wave to finish publishes the region's survivor count (LDS atomics of one CU are ordered)
-        if (atomicAdd(&q_done, 1u) == W - 1) a.seg_out[seg] = atomicAdd(&q_out, 0u);
-    }
-}
-
 // ---- k_walk: ONE launch walks every remaining bounce (brute-force kernels) -----------------------------------------------
 // Compaction is local to the segment, so nothing forces a grid-wide barrier between bounces: the workgroup that owns a
 // segment carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers (release
@@ -982,7 +718,7 @@ __global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const Rad
     };
     leave_if_idle(cnt_in);
     const uint32_t live_threads = (min(cnt_in, SEG) + 63u) & ~63u;  // waves present at the first trip
-    const LdsScene ls = {nullptr, nullptr, nullptr};
+    const LdsScene ls = NO_LDS_SCENE;
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     if (ACCEL == ACCEL_K_BRUTE && FIRST) fill_tables_lds(a.sc, tab_lds, live_threads);
     const uint32_t cap = a.cap;
@@ -1137,7 +873,7 @@ __global__ __launch_bounds__(REGEN_WG, REGEN_WAVES_PER_EU) void k_regen(const Ra
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     __shared__ uint32_t hist[W][MAX_DEPTH_STATS + 2];  // per wave: paths that ended after d + 1 bounces
     const uint32_t tid = threadIdx.x, wid = tid >> 6, lane = tid & 63u;
-    const LdsScene ls = {nullptr, nullptr, nullptr};
+    const LdsScene ls = NO_LDS_SCENE;
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     hist[wid][lane] = 0;  // MAX_DEPTH_STATS + 2 == 64
     if (ACCEL == ACCEL_K_BRUTE)

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         if (tid == 0) a.seg_out[seg] = 0;
         return;
     }
-    LdsScene ls = {nullptr, nullptr, nullptr};
+    BVH_STACK_LDS(ACCEL, SEG);
+    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, SEG)};
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
@@ -410,7 +411,8 @@ __global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_ray
     const uint32_t ang = ray_id / NE, el = ray_id - ang * NE;
     const V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));            // :270,273
     const V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);          // :271,273
-    LdsScene ls = {nullptr, nullptr, nullptr};
+    BVH_STACK_LDS(ACCEL, 256);
+    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, 256)};
     Hit h;
     const bool hit = scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h);
     if (recv == 0) {
@@ -460,7 +462,8 @@ __global__ __launch_bounds__(256) void k_ray_intersect(DevScene sc, uint32_t n, 
                                                        const float *tmax, float *t, uint32_t *prim, float *u, float *v) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    LdsScene ls = {nullptr, nullptr, nullptr};
+    BVH_STACK_LDS(ACCEL, 256);
+    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, 256)};
     Hit h;
     bool f = scene_intersect<ACCEL, false>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
                                            tmax[i], &h);
@@ -475,7 +478,8 @@ __global__ __launch_bounds__(256) void k_ray_test(DevScene sc, uint32_t n, const
                                                   const float *tmax, uint8_t *hit) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    LdsScene ls = {nullptr, nullptr, nullptr};
+    BVH_STACK_LDS(ACCEL, 256);
+    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, 256)};
     Hit h;
     hit[i] = scene_intersect<ACCEL, true>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
                                           tmax[i], &h)

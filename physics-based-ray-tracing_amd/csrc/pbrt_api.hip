@@ -74,6 +74,7 @@ struct pbrt_scene {
     DevScene ds{};
     int accel_kernel = ACCEL_K_BRUTE;
     uint32_t lds_bytes = 0;
+    uint32_t bvh_depth = 0;  // levels of inner nodes of the BVH4
     std::vector<void *> allocs;
     pbrt_material *d_mats = nullptr;
     uint32_t n_mats = 0;
@@ -336,7 +337,7 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
                           (d->accel == PBRT_ACCEL_AUTO && d->n_prims > 32);
     if (!want_bvh) {
         s->ds.prims = d_prims_by_id;
-        s->ds.prim_ids = nullptr;
+        s->ds.lprims = nullptr;
         s->ds.nodes = nullptr;
         s->ds.n_nodes = 0;
         bool small = d->n_prims <= TAB_MAX && d->n_materials <= TAB_MAX && d->n_emitters <= TAB_MAX;
@@ -358,31 +359,30 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     } else {
         HostBvh bvh;
         build_bvh(d->prims, d->n_prims, &bvh);
-        if (bvh.max_depth > 60 || bvh.nodes.size() >= (1u << 24)) {  // 64-bit trail; ring entries: node | level << 24
+        HostBvh4 b4;
+        to_bvh4(bvh, &b4);
+        // traversal stack: at most three entries per level of inner nodes (device_scene.h BvhStack)
+        if (3u * b4.depth + 1u > BVH_STK_MAX || b4.nodes.size() >= (1u << 31) || d->n_prims >= (1u << 27)) {
             pbrt_scene_destroy(s);
-            return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u / %zu nodes exceed the traversal state", bvh.max_depth,
-                           bvh.nodes.size());
+            return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u / %zu nodes exceed the traversal state", b4.depth, b4.nodes.size());
         }
-        std::vector<pbrt_prim> ordered(d->n_prims);
-        for (uint32_t k = 0; k < d->n_prims; ++k) ordered[k] = d->prims[bvh.order[k]];
-        UP(upload(s, ordered.data(), ordered.size(), &s->ds.prims));
-        UP(upload(s, bvh.order.data(), bvh.order.size(), &s->ds.prim_ids));
-        if (d->vertex_normals) {  // in leaf order, like the primitives: make_si indexes them by Hit::slot
-            std::vector<float> vn((size_t)d->n_prims * 9);
-            for (uint32_t k = 0; k < d->n_prims; ++k)
-                std::memcpy(&vn[(size_t)k * 9], d->vertex_normals + (size_t)bvh.order[k] * 9, 36);
-            UP(upload(s, vn.data(), vn.size(), &s->ds.vnormals));
-        }
-        std::vector<HostInner> inner;
-        to_inner_nodes(bvh, &inner);
-        static_assert(sizeof(HostInner) == sizeof(DevNode), "node layout");
-        const DevNode *dn = nullptr;
-        UP(upload(s, reinterpret_cast<const DevNode *>(inner.data()), inner.size(), &dn));
+        std::vector<HostLeafPrim> lp;
+        make_leaf_prims(d->prims, bvh.order, &lp);
+        static_assert(sizeof(HostLeafPrim) == sizeof(DevLeafPrim) && sizeof(DevLeafPrim) == 40, "leaf record layout");
+        static_assert(sizeof(HostNode4) == sizeof(DevNode4) && sizeof(DevNode4) == 64, "node layout");
+        s->ds.prims = d_prims_by_id;  // Hit::slot is the caller's index
+        const DevLeafPrim *dl = nullptr;
+        UP(upload(s, reinterpret_cast<const DevLeafPrim *>(lp.data()), lp.size(), &dl));
+        s->ds.lprims = dl;
+        if (d->vertex_normals) UP(upload(s, d->vertex_normals, (size_t)d->n_prims * 9, &s->ds.vnormals));
+        const DevNode4 *dn = nullptr;
+        UP(upload(s, reinterpret_cast<const DevNode4 *>(b4.nodes.data()), b4.nodes.size(), &dn));
         s->ds.nodes = dn;
-        s->ds.n_nodes = (uint32_t)inner.size();
-        size_t lds = inner.size() * sizeof(DevNode) + (size_t)d->n_prims * (sizeof(pbrt_prim) + 4);
-        // static LDS of the bounce kernels: 3 * SEG/64 dwords; keep 1 KiB of slack
-        if (c->lds_limit && lds + 1024 <= c->lds_limit && d->accel != PBRT_ACCEL_BVH_GLOBAL) {
+        s->ds.n_nodes = (uint32_t)b4.nodes.size();
+        s->bvh_depth = b4.depth;
+        const size_t lds = b4.nodes.size() * sizeof(DevNode4) + (size_t)d->n_prims * sizeof(DevLeafPrim);
+        // beside the image: the traversal stacks of a 1024-thread workgroup and the kernels' small static arrays (1 KiB of slack)
+        if (c->lds_limit && lds + BVH_STK_DW(SEG_BVH) * 4 + 1024 <= c->lds_limit && d->accel != PBRT_ACCEL_BVH_GLOBAL) {
             s->accel_kernel = ACCEL_K_BVH_LDS;
             s->lds_bytes = (uint32_t)((lds + 15) & ~size_t(15));
         } else {
@@ -468,13 +468,6 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32
     }
 }
 
-// k_bounce_pool keeps its hit stacks (POOL_BYTES) in LDS beside the scene image: scenes whose image leaves no room for them
-// stay with k_bounce for every bounce
-static bool hit_pool_fits(const pbrt_scene *s) {
-    if (s->accel_kernel == ACCEL_K_BVH_GLOBAL) return true;
-    return s->accel_kernel == ACCEL_K_BVH_LDS && (size_t)s->lds_bytes + POOL_BYTES + 1024 <= s->ctx->lds_limit;
-}
-
 static int set_lds_attr(pbrt_scene *s) {
     if (s->accel_kernel != ACCEL_K_BVH_LDS) return PBRT_OK;
     pbrt_ctx *c = s->ctx;
@@ -483,9 +476,6 @@ static int set_lds_attr(pbrt_scene *s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    if (hit_pool_fits(s))
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce_pool<ACCEL_K_BVH_LDS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<true, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<false, ACCEL_K_BVH_LDS>),
@@ -595,8 +585,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
     // k_bounce_pool launches also count the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
-    const bool hit_pool = (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) &&
-                          !(f->flags & PBRT_FILM_NO_HIT_POOL) && hit_pool_fits(s);
+    const bool hit_pool = false;
     const uint32_t hit_rows = hit_pool ? stat_rows - 2 : 0;
     if (repack && (!stC || !segC || !offs || !quota)) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
@@ -712,12 +701,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 HIPCHK(c, hipEventRecord(e0, st));
             }
             const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
-            if (hit_pool && depth >= 1) {
-                if (s->accel_kernel == ACCEL_K_BVH_GLOBAL)
-                    hipLaunchKernelGGL(k_bounce_pool<ACCEL_K_BVH_GLOBAL>, dim3(nseg_pass), dim3(SEG_BVH), 0, st, a);
-                else
-                    hipLaunchKernelGGL(k_bounce_pool<ACCEL_K_BVH_LDS>, dim3(nseg_pass), dim3(SEG_BVH), s->lds_bytes, st, a);
-            } else if (walk) {
+            if (walk) {
                 if (depth == 0)
                     launch_walk<true>(s, a, nseg_pass, nb);
                 else

@@ -13,6 +13,7 @@
 
 #include "bvh_build.h"
 #include "kernels_us.h"
+#include "kernels_wavefront.h"
 #include "kernels_beamform.h"
 
 static std::string g_ctxless_error;
@@ -530,6 +531,152 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
              film_px * 28 /* resolve */;
 }
 
+
+// ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
+struct WfPlan {
+    uint32_t threads = 1024, rows = 2, grid_mult = 4;
+    size_t lds = 0;
+};
+// Workgroup shape of k_trace: the image plus (rows + 1) stack rows per workgroup; two 1024-thread workgroups per CU when both fit
+// (8 waves per SIMD at <= 64 VGPRs), else one.  PBRT_WF_THREADS / PBRT_WF_ROWS / PBRT_WF_GRID_MULT override (diagnostic A/B).
+static WfPlan wf_plan(const pbrt_scene *s) {
+    WfPlan p;
+    static const char *e_thr = getenv("PBRT_WF_THREADS"), *e_rows = getenv("PBRT_WF_ROWS"), *e_grid = getenv("PBRT_WF_GRID_MULT");
+    const uint32_t limit = s->ctx->lds_limit ? s->ctx->lds_limit : 65536u;
+    const uint32_t image = s->accel_kernel == ACCEL_K_BVH_LDS ? s->lds_bytes : 0u;
+    p.threads = image ? 1024u : 256u;
+    if (e_thr) p.threads = std::min(1024u, std::max(64u, (uint32_t)atoi(e_thr) & ~63u));
+    const uint32_t statics = 1024;  // queue words and the segment table, with slack
+    uint32_t budget = limit / 2;     // two workgroups per CU
+    if (image + statics + 3u * p.threads * 4u > budget) budget = limit;
+    uint32_t rows_total = (budget - image - statics) / (p.threads * 4u);
+    p.rows = std::max(2u, std::min(rows_total - 1u, 8u));
+    if (e_rows) p.rows = std::max(2u, std::min((uint32_t)atoi(e_rows), 15u));
+    if (e_grid) p.grid_mult = std::max(1u, (uint32_t)atoi(e_grid));
+    p.lds = (size_t)image + (size_t)(p.rows + 1u) * p.threads * 4u;
+    return p;
+}
+static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
+    pbrt_ctx *c = s->ctx;
+    if (s->accel_kernel == ACCEL_K_BVH_LDS) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<true, ACCEL_K_BVH_LDS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<false, ACCEL_K_BVH_LDS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    }
+    return PBRT_OK;
+}
+struct WfBufs {
+    float4 *stA, *stB, *hits, *shA, *shB;
+    uint32_t *segA, *segB, *nshA, *nshB;
+};
+static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
+    b->stA = (float4 *)c->buf("wf_stateA", (size_t)cap * 64);
+    b->stB = (float4 *)c->buf("wf_stateB", (size_t)cap * 64);
+    b->hits = (float4 *)c->buf("wf_hits", (size_t)cap * 16);
+    b->shA = (float4 *)c->buf("wf_shadowA", (size_t)cap * 64);
+    b->shB = (float4 *)c->buf("wf_shadowB", (size_t)cap * 64);
+    b->segA = (uint32_t *)c->buf("wf_segA", (size_t)nreg * 4);
+    b->segB = (uint32_t *)c->buf("wf_segB", (size_t)nreg * 4);
+    b->nshA = (uint32_t *)c->buf("wf_nshA", (size_t)nreg * 4);
+    b->nshB = (uint32_t *)c->buf("wf_nshB", (size_t)nreg * 4);
+    return b->stA && b->stB && b->hits && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
+}
+// The bounces of one pass.  camera: depth 0 generates its rays from the film keys (else the rays are in b.stA / b.segA).
+// Returns the number of launches through *launches.
+static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p, uint32_t nreg, bool camera, uint32_t *launches) {
+    pbrt_ctx *c = s->ctx;
+    hipStream_t st = c->stream;
+    const bool lds = s->accel_kernel == ACCEL_K_BVH_LDS;
+    const uint32_t G = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_mult * (uint32_t)c->n_cu));
+    a.n_regions = nreg;
+    a.lds_bytes = lds ? s->lds_bytes : 0u;
+    a.stk_rows = p.rows;
+    float4 *in = b.stA, *out = b.stB, *shi = b.shA, *sho = b.shB;
+    uint32_t *sin = b.segA, *sout = b.segB, *ni = b.nshA, *no = b.nshB;
+    auto one = [&](uint32_t depth, bool first, bool have_shadows) {
+        a.depth = depth;
+        a.st_in = in;
+        a.st_out = out;
+        a.hits = b.hits;
+        a.shd_in = shi;
+        a.shd_out = sho;
+        a.seg_in = sin;
+        a.seg_out = sout;
+        a.nsh_in = have_shadows ? ni : nullptr;
+        a.nsh_out = no;
+        if (first) {
+            if (lds)
+                hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
+            else
+                hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
+            hipLaunchKernelGGL((k_shade<true, ACCEL_K_BVH_GLOBAL>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+        } else {
+            if (lds)
+                hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
+            else
+                hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
+            hipLaunchKernelGGL((k_shade<false, ACCEL_K_BVH_GLOBAL>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+        }
+        *launches += 2;
+        std::swap(in, out);
+        std::swap(shi, sho);
+        std::swap(sin, sout);
+        std::swap(ni, no);
+    };
+    bool flush = false;
+    for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
+        one(depth, camera && depth == 0, depth > 0);
+        HIPCHK(c, hipGetLastError());
+        // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces
+        if (a.max_depth > 32 && (depth & 7u) == 7u) {
+            std::vector<uint32_t> cnt(nreg);
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nreg * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(c, hipStreamSynchronize(st));
+            uint64_t live = 0;
+            for (uint32_t v : cnt) live += v;
+            if (live == 0) {
+                flush = depth + 1 < a.max_depth;  // the last bounce may have left shadow rays behind
+                a.depth = depth + 1;
+                break;
+            }
+        }
+    }
+    if (flush) {
+        one(a.depth, false, true);
+        HIPCHK(c, hipGetLastError());
+    }
+    return PBRT_OK;
+}
+// after the stream has drained: did a wave of k_trace run into its turn guard?
+static int wf_check_guard(pbrt_ctx *c) {
+    uint32_t g[16];
+    HIPCHK(c, hipMemcpyFromSymbol(g, HIP_SYMBOL(g_wf_guard), sizeof g));
+    if (g[0] == 0) return PBRT_OK;
+    const uint32_t z[16] = {0};
+    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wf_guard), z, sizeof z));
+    return c->fail(PBRT_E_DEVICE,
+                   "k_trace: %u wave(s) hit the turn guard (block %u wave %u: busy %u walking %u prefetched %u queue_empty %u total %u "
+                   "q_in %u visits %u depth 0x%x K %u)",
+                   g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11]);
+}
+
+// Byte model of the two-launch bounce: k_trace reads 32 B per ray and writes a 16-B hit or a 4-B visibility;
+// k_shade reads the hit records, the state of the paths that hit something (64 B; the camera ray is regenerated at depth 0),
+// 32 B of the ones that did not, writes 64 B per survivor and per shadow ray, 16 B per path that ends, and applies a shadow
+// ray with 64 + 32 B.  live[d] = rays of depth d, hits[d] = those that hit something, shadows = shadow rays of the render.
+static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsigned long long *hits, uint32_t nd, uint64_t shadows) {
+    uint64_t b = 0;
+    for (uint32_t d = 0; d < nd; ++d) {
+        const uint64_t in = live[d], next = d + 1 < nd ? live[d + 1] : 0, h = hits[d];
+        if (!in) break;
+        b += (d > 0 ? in * 32 : 0) + in * 16;                             // k_trace
+        b += in * 16 + (d > 0 ? (in - h) * 32 + h * 64 : 0);              // k_shade: hit records, state
+        b += (in - next) * 16 + next * 64;                                // radiance records, survivors
+    }
+    return b + shadows * (36 + 64 + 96);
+}
+
 static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
     pbrt_ctx *c = s->ctx;
     NEED(c, cam && f && d_out);
@@ -561,12 +708,24 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
     const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
     NEED(c, (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the state arrays are addressed through 32-bit buffer offsets
-    float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
-    float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    // BVH scenes: intersection and shading as separate streams (kernels_wavefront.h); PBRT_FILM_NO_HIT_POOL keeps the fused
+    // k_bounce (one launch per bounce, shading in the lanes the traversal leaves) as the A/B reference
+    const bool bvh_scene = s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS;
+    const bool wavefront = bvh_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
+    static_assert(WF_REGION == REGION_SEGS_BVH * SEG_BVH, "both BVH launch structures cut a pass into the same regions");
+    WfBufs wfb{};
+    WfPlan wfp;
+    if (wavefront) {
+        NEED(c, cap < 0x80000000u);  // shadow records address a home with bit 31 as the flag
+        if (!wf_alloc(c, cap, nseg, &wfb)) return PBRT_E_NOMEM;
+        wfp = wf_plan(s);
+        if ((rc = wf_set_attr(s, wfp)) != 0) return rc;
+    }
+    float *stA = wavefront ? (float *)wfb.stA : (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
+    float *stB = wavefront ? (float *)wfb.stB : (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
-    // BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
-    const bool repack = (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) &&
-                        rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
+    // fused BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
+    const bool repack = bvh_scene && !wavefront && rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
     float *stC = repack ? (float *)c->buf("stateC", (size_t)cap * N_STATE * 4) : nullptr;
     // live counters and statistics rows: one per region, or one per wave of it (BVH kernels: wave-private compaction)
     const uint32_t n_own = nseg * rad_owners_per_region(s->accel_kernel);
@@ -577,7 +736,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t *quota = repack ? (uint32_t *)c->buf("seg_quota", 64) : nullptr;
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + 2 * MAX_DEPTH_STATS) * 8);
-    const uint32_t n_rows = nseg * rad_rows_per_region(s->accel_kernel);         // statistics rows
+    const uint32_t n_rows = nseg * (wavefront ? 1u : rad_rows_per_region(s->accel_kernel));  // statistics rows
     // statistics rows in use: segments, shadow rays, one per depth (cleared and reduced per call: keep it to what the call touches)
     const uint32_t stat_rows = 2 + (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS);
     const size_t segstats_bytes = (size_t)stat_rows * n_rows * 8;  // reduced at the end
@@ -585,7 +744,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     if (!segstats) return PBRT_E_NOMEM;
     if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
     // k_bounce_pool launches also count the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
-    const bool hit_pool = false;
+    const bool hit_pool = wavefront;  // k_shade counts the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
     const uint32_t hit_rows = hit_pool ? stat_rows - 2 : 0;
     if (repack && (!stC || !segC || !offs || !quota)) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
@@ -647,7 +806,36 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
         const uint32_t fuse_plan = call_plan;
         const uint32_t walk_from = (f->flags & PBRT_FILM_WALK_SET) ? ((f->flags >> 17) & 0xffu) : PBRT_DEFAULT_WALK_FROM;
-        if (brute && (f->flags & PBRT_FILM_REGEN)) {
+        if (wavefront) {
+            WfArgs w{};
+            w.sc = a.sc;
+            w.cam = a.cam;
+            w.Lhome = Lhome;
+            w.stats = segstats;
+            w.stat_stride = n_rows;
+            w.cap = cap;
+            w.n_paths = a.n_paths;
+            w.max_depth = a.max_depth;
+            w.rr_depth = a.rr_depth;
+            w.seed = a.seed;
+            w.key_mode = 0;
+            w.rx0 = a.rx0;
+            w.ry0 = a.ry0;
+            w.rw = a.rw;
+            w.npix_r = a.npix_r;
+            w.s_first = a.s_first;
+            w.film_w = a.film_w;
+            w.film_h = a.film_h;
+            w.tile_rows = a.tile_rows;
+            w.div_npix = a.div_npix;
+            w.div_rw = a.div_rw;
+            pass_e1 = c->event(n_ev + 1);
+            hipEvent_t e0 = c->event(n_ev);
+            if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+            n_ev += 2;
+            HIPCHK(c, hipEventRecord(e0, st));
+            if ((rc = wf_bounces(s, w, wfb, wfp, nseg_pass, true, &launches)) != 0) return rc;
+        } else if (brute && (f->flags & PBRT_FILM_REGEN)) {
             // persistent waves with path regeneration (k_regen): one launch per pass, as many workgroups as the GPU holds at once
             int per_cu = 0;
             const void *fn = s->accel_kernel == ACCEL_K_BRUTE ? reinterpret_cast<const void *>(&k_regen<ACCEL_K_BRUTE>)
@@ -792,6 +980,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    if (wavefront && (rc = wf_check_guard(c)) != 0) return rc;
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;
@@ -819,6 +1008,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     }
     radiance_model_bytes(hstats + 2, MAX_DEPTH_STATS, S.samples, film_px, passes, plan, f->max_depth,
                          hit_pool ? hstats + HIT_ROW0 : nullptr, &tot, &bb);
+    if (wavefront) {
+        tot -= bb;
+        bb = wavefront_model_bytes(hstats + 2, hstats + HIT_ROW0, MAX_DEPTH_STATS, S.shadow_rays);
+        tot += bb;
+    }
     if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written
         tot -= bb;
         bb = S.samples * 12;
@@ -873,6 +1067,50 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     if (rc) return rc;
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
+    if (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) {  // trace / shade streams
+        NEED(c, cap < 0x80000000u);
+        WfBufs b{};
+        if (!wf_alloc(c, cap, nseg, &b)) return PBRT_E_NOMEM;
+        const WfPlan p = wf_plan(s);
+        if ((rc = wf_set_attr(s, p)) != 0) return rc;
+        float *Lh = (float *)c->buf("Lhome", (size_t)cap * 16);
+        unsigned long long *rows = (unsigned long long *)c->buf("segstats", (size_t)(2 + 2 * MAX_DEPTH_STATS) * nseg * 8);
+        float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
+        if (!Lh || !rows || !io) return PBRT_E_NOMEM;
+        hipStream_t st = c->stream;
+        HIPCHK(c, hipMemcpyAsync(io, o, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(io + 3 * (size_t)n, d, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(c, hipMemsetAsync(rows, 0, (size_t)(2 + 2 * MAX_DEPTH_STATS) * nseg * 8, st));
+        HIPCHK(c, hipMemsetAsync(Lh, 0, (size_t)cap * 16, st));
+        hipLaunchKernelGGL(k_init_rays_wf, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, b.stA, b.segA, nseg, n, io,
+                           io + 3 * (size_t)n, io + 6 * (size_t)n);
+        WfArgs w{};
+        w.sc = s->ds;
+        w.Lhome = Lh;
+        w.stats = rows;
+        w.stat_stride = nseg;
+        w.cap = cap;
+        w.n_paths = n;
+        w.max_depth = max_depth;
+        w.rr_depth = rr_depth;
+        w.seed = seed;
+        w.key_mode = 1;
+        w.npix_r = 1;
+        w.rw = 1;
+        w.div_npix = w.div_rw = make_fastdiv(1);
+        w.index_offset = index_offset;
+        w.sample_index = sample_index;
+        uint32_t launches = 0;
+        if ((rc = wf_bounces(s, w, b, p, nseg, false, &launches)) != 0) return rc;
+        HIPCHK(c, hipStreamSynchronize(st));
+        if ((rc = wf_check_guard(c)) != 0) return rc;
+        std::vector<float> rec((size_t)n * 4);
+        HIPCHK(c, hipMemcpy(rec.data(), Lh, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) rgb[(size_t)k * n + i] = rec[(size_t)i * 4 + k];
+        return PBRT_OK;
+    }
     float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
     float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home

@@ -375,63 +375,87 @@ DEV bool brute_closest_pairs(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h)
 // does not depend on the tree or on the visiting order.
 //
 // Slab form: a child plane sits at org + q * step (q = 0..255), so  t = (org + q step - o) / d = q * A + B  with
-// A = step * (1/d) and B = org * (1/d) - o * (1/d) per node and axis: one v_cvt_f32_ubyte + one fma per plane.  The
+// A = step * (1/d) and B = (org - o) * (1/d) per node and axis: one v_cvt_f32_ubyte + one fma per plane.  The
 // rounding error is that of moving the plane by a few 2^-23 * (|plane| + |o|), two orders of magnitude inside the
 // builder's padding (2e-5 * scene size, bvh_build.h), so a box the exact test accepts is never culled.  A zero direction
 // component would make the products infinite (inf - inf = NaN hides the slab, but -inf - inf = -inf culls a box the ray is
 // inside of), so components below 1e-18 are replaced by +-1e-18 for the box tests only: all products stay finite and the
 // sign of (plane - o) survives for every plane further than the padding from the ray.
 struct BoxRay {
-    V3 oi, inv;  // o / d, 1 / d
+    V3 o, inv;  // origin (shared with the primitive tests), 1 / d
 };
 DEV BoxRay make_box_ray(V3 o, V3 d) {
     const float tiny = 1e-18f;
     const V3 ds = {fabsf(d.x) < tiny ? copysignf(tiny, d.x) : d.x, fabsf(d.y) < tiny ? copysignf(tiny, d.y) : d.y,
                    fabsf(d.z) < tiny ? copysignf(tiny, d.z) : d.z};
-    const V3 inv = {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z)};
-    return {{o.x * inv.x, o.y * inv.y, o.z * inv.z}, inv};
+    return {o, {__builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y), __builtin_amdgcn_rcpf(ds.z)}};
 }
 
-// Per-lane traversal stack: the newest entry lives in a register (`tos`), rows 0 .. n_rows - 1 of an LDS array
-// [row][thread] hold the next ones (row n_rows is a scratch row for the branch-free push), anything deeper goes to a
-// private array (scratch memory; the host checks that 3 * depth + 1 <= BVH_STK_MAX).  A pop hands out `tos` and requests
-// the next entry right away, so its LDS latency is covered by the node test that follows.
-#define BVH_STK_OVF 40
+// Per-lane traversal stack.  An entry stands for ONE node whose other hit children are still to be visited:
+//   node index << 8 | count (1..3) << 6 | slots of those children in the order of their entry distances, 2 bits each, the
+//   next one in bits 1..0
+// so the stack is never deeper than the tree (one entry per level), and taking the next child of the newest entry is register
+// arithmetic plus one 4-byte read of the node's child reference.  The newest entry lives in a register (`tos`), rows
+// 0 .. n_rows - 1 of an LDS array [row][thread] (threads a power of two: the row offset is a shift) hold the next ones,
+// anything deeper goes to a private array in scratch memory (volatile: its accesses must stay apart from the LDS ones -- merged
+// into one FLAT access through a selected pointer they would no longer be ordered against the DS instructions).  The bottom
+// of the stack is BVH_SENT: the first push stores it in row 0, the last pop brings it back.  The host checks
+// depth <= BVH_STK_MAX and nodes < 2^24.
+#define BVH_STK_OVF 30
 #define BVH_STK_MAX (BVH_STK_OVF + 2)  // guaranteed capacity whatever n_rows is (>= 2 rows are always there)
 struct BvhStack {
-    uint32_t *col;     // this thread's column: entry of row r at col[r * stride]; nullptr: brute-force kernels
-    uint32_t stride;   // threads of the workgroup
-    uint32_t n_rows;   // rows that hold entries (>= 2); one more row exists behind them
+    uint32_t *col;     // this thread's column: entry of row r at col[r << shift]; nullptr: brute-force kernels
+    uint32_t shift;    // log2(threads of the workgroup)
+    uint32_t n_rows;   // LDS rows (>= 2)
 };
 struct BvhCursor {
     uint32_t cur, tos, sp;
-    uint32_t ovf[BVH_STK_OVF];
 };
-DEV void bvh_push(const BvhStack &st, BvhCursor &c, bool on, uint32_t ref) {
+typedef volatile uint32_t BvhOvf[BVH_STK_OVF];
+DEV void bvh_push(const BvhStack &st, BvhCursor &c, BvhOvf &ovf, bool on, uint32_t entry) {
     if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // wave-uniform
-    st.col[min(c.sp, st.n_rows) * st.stride] = c.tos;   // lanes that do not push write above their top / into the scratch row
-    if (on && c.sp >= st.n_rows) c.ovf[min(c.sp - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)] = c.tos;
-    c.sp += on ? 1u : 0u;
-    c.tos = on ? ref : c.tos;
+    if (on) {
+        if (c.sp < st.n_rows)
+            st.col[c.sp << st.shift] = c.tos;
+        else
+            ovf[min(c.sp - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)] = c.tos;
+        c.sp += 1u;
+        c.tos = entry;
+    }
 }
-DEV uint32_t bvh_pop(const BvhStack &st, BvhCursor &c) {
-    const uint32_t r = c.tos;
-    const bool has = c.sp > 0;
-    const uint32_t sp1 = has ? c.sp - 1u : 0u;
-    uint32_t nxt = st.col[min(sp1, st.n_rows - 1u) * st.stride];
-    if (has && sp1 >= st.n_rows) nxt = c.ovf[min(sp1 - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)];
-    c.tos = has ? nxt : BVH_SENT;
-    c.sp = sp1;
-    return r;
+// the next child reference off the stack (BVH_SENT: the traversal has finished)
+template <typename NodeP>
+DEV uint32_t bvh_pop(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf) {
+    const uint32_t e = c.tos;
+    if (e == BVH_SENT) return BVH_SENT;
+    const uint32_t ref = nodes[e >> 8].child[e & 3u];
+    const uint32_t n = (e >> 6) & 3u;
+    if (n > 1u) {
+        c.tos = (e & 0xffffff00u) | ((n - 1u) << 6) | ((e & 0x3fu) >> 2);
+    } else {  // the entry is used up: the next one comes off the rows (nothing reads it before the next pop or push)
+        const uint32_t sp1 = c.sp - 1u;  // (sp >= 1: BVH_SENT lies below every entry)
+        if (sp1 < st.n_rows)
+            c.tos = st.col[sp1 << st.shift];
+        else
+            c.tos = ovf[min(sp1 - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)];
+        c.sp = sp1;
+    }
+    return ref;
 }
 
-// One inner node: the four child boxes against the ray, the nearest hit child becomes the cursor, the others are pushed
-// (in index order, reversed for rays that run against the node's split axis: about front to back), no hit pops.
+// One inner node: the four child boxes against the ray; the slots of the hit children sorted by entry distance (a
+// 5-exchange network on distance | slot keys); the nearest becomes the cursor, the others one stack entry; no hit pops.
+DEV void bvh_cex(uint32_t &ka, uint32_t &kb) {
+    const uint32_t lo = min(ka, kb), hi = max(ka, kb);
+    ka = lo;
+    kb = hi;
+}
 template <typename NodeP>
-DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, const BoxRay &r, float best) {
+DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, const BoxRay &r, float best) {
     typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
     typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
-    const auto *np = nodes + c.cur;
+    const uint32_t node = c.cur;
+    const auto *np = nodes + node;
     const u32x4 w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
     const u32x4 w1 = *reinterpret_cast<const u32x4 *>(&np->child[0]);
     const u32x4 w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
@@ -439,8 +463,8 @@ DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, const BoxRay &
     const uint32_t exps = w0.w;
     const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
                 Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
-    const float Bx = fma_(__uint_as_float(w0.x), r.inv.x, -r.oi.x), By = fma_(__uint_as_float(w0.y), r.inv.y, -r.oi.y),
-                Bz = fma_(__uint_as_float(w0.z), r.inv.z, -r.oi.z);
+    const float Bx = (__uint_as_float(w0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(w0.y) - r.o.y) * r.inv.y,
+                Bz = (__uint_as_float(w0.z) - r.o.z) * r.inv.z;
     const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
     const uint32_t qnx = nx ? w2.w : w2.x, qfx = nx ? w2.x : w2.w;   // planes the ray enters / leaves through
     const uint32_t qny = ny ? w3.x : w2.y, qfy = ny ? w2.y : w3.x;
@@ -455,22 +479,21 @@ DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, const BoxRay &
         const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
         key[k] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : 0xffffffffu;  // tn >= 0: ordered like the floats
     }
-    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
-    const uint32_t near = kmin & 3u;
-    const bool h0 = key[0] != 0xffffffffu && near != 0u, h1 = key[1] != 0xffffffffu && near != 1u,
-               h2 = key[2] != 0xffffffffu && near != 2u, h3 = key[3] != 0xffffffffu && near != 3u;
-    // push the others so that the one met first along the split axis is popped first
-    const uint32_t axis = (exps >> 24) & 3u;
-    const bool rev = axis == 0u ? nx : (axis == 1u ? ny : nz);
-    bvh_push(st, c, rev ? h0 : h3, rev ? w1.x : w1.w);
-    bvh_push(st, c, rev ? h1 : h2, rev ? w1.y : w1.z);
-    bvh_push(st, c, rev ? h2 : h1, rev ? w1.z : w1.y);
-    bvh_push(st, c, rev ? h3 : h0, rev ? w1.w : w1.x);
-    if (kmin == 0xffffffffu) {
-        c.cur = bvh_pop(st, c);
-    } else {
-        c.cur = near == 0u ? w1.x : (near == 1u ? w1.y : (near == 2u ? w1.z : w1.w));
+    bvh_cex(key[0], key[1]);
+    bvh_cex(key[2], key[3]);
+    bvh_cex(key[0], key[2]);
+    bvh_cex(key[1], key[3]);
+    bvh_cex(key[1], key[2]);
+    if (key[0] == 0xffffffffu) {
+        c.cur = bvh_pop(nodes, st, c, ovf);
+        return;
     }
+    const uint32_t s0 = key[0] & 3u;
+    c.cur = s0 == 0u ? w1.x : (s0 == 1u ? w1.y : (s0 == 2u ? w1.z : w1.w));
+    const uint32_t n_more = (key[1] != 0xffffffffu ? 1u : 0u) + (key[2] != 0xffffffffu ? 1u : 0u) + (key[3] != 0xffffffffu ? 1u : 0u);
+    // (slots of misses are 3, 3, ...: never looked at, the count says how many are real)
+    const uint32_t entry = (node << 8) | (n_more << 6) | (key[1] & 3u) | ((key[2] & 3u) << 2) | ((key[3] & 3u) << 4);
+    bvh_push(st, c, ovf, n_more != 0u, entry);
 }
 
 // One leaf record against the ray (`full`: the 64-byte table, read for cones only)
@@ -509,6 +532,7 @@ template <bool ANY, typename NodeP, typename PrimP>
 DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const BvhStack &st, V3 o, V3 d, float tmax, Hit *h) {
     const BoxRay br = make_box_ray(o, d);
     BvhCursor c;
+    BvhOvf ovf;
     c.cur = 0;
     c.tos = BVH_SENT;
     c.sp = 0;
@@ -520,7 +544,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
             atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 1], 1ull);
             if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 0], 64ull);
 #endif
-            bvh_visit(nodes, st, c, br, best);
+            bvh_visit(nodes, st, c, ovf, br, best);
         }
         if (c.cur == BVH_SENT) break;  // this lane has finished (the wave leaves the loop when every lane has)
         const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
@@ -544,7 +568,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
                 }
             }
         }
-        c.cur = bvh_pop(st, c);
+        c.cur = bvh_pop(nodes, st, c, ovf);
     }
     return found;
 }

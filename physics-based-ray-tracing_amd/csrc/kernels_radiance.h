@@ -211,14 +211,17 @@ struct LdsScene {
     BvhStack stk;
 };
 #ifndef BVH_STK_ROWS
-#define BVH_STK_ROWS 4  // LDS rows of the traversal stacks of the fused kernels (+ 1 scratch row); deeper entries go to scratch memory
+#define BVH_STK_ROWS 4  // LDS rows of the traversal stacks of the fused kernels; deeper entries go to scratch memory
 #endif
-#define BVH_STK_DW(threads) ((BVH_STK_ROWS + 1) * (threads))
-DEV BvhStack make_bvh_stack(uint32_t *lds, uint32_t threads) { return {lds + threadIdx.x, threads, BVH_STK_ROWS}; }
+#define BVH_STK_DW(threads) (BVH_STK_ROWS * (threads))
+__host__ __device__ constexpr uint32_t ilog2_c(uint32_t v) { return v <= 1u ? 0u : 1u + ilog2_c(v >> 1); }
+// threads: the workgroup size, a power of two
+#define MAKE_BVH_STACK(lds, threads) BvhStack{(lds) + threadIdx.x, ilog2_c(threads) + 0u, BVH_STK_ROWS}
 // static LDS of a kernel that may walk a BVH: its traversal stacks (one dword for the brute-force variants)
-#define BVH_STACK_LDS(ACCEL, THREADS) \
+#define BVH_STACK_LDS(ACCEL, THREADS)                                                                              \
+    static_assert(((THREADS) & ((THREADS)-1)) == 0, "BVH stack rows are addressed by a shift");                    \
     __shared__ uint32_t bvh_stk_lds[((ACCEL) == ACCEL_K_BVH_GLOBAL || (ACCEL) == ACCEL_K_BVH_LDS) ? BVH_STK_DW(THREADS) : 1]
-#define NO_LDS_SCENE {nullptr, nullptr, {nullptr, 0u, 0u}}
+#define NO_LDS_SCENE {nullptr, nullptr, BvhStack{nullptr, 0u, 0u}}
 
 // SEGMENT: the ray is a segment between two points of the scene (next-event shadow ray): brute-force
 // scenes then only walk the primitives that can occlude such a segment (DevScene::occ_prims).
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     }
     const uint32_t live_threads = early_exit ? (min(cnt_in, SEG) + 63u) & ~63u : SEG;  // waves still present
     BVH_STACK_LDS(ACCEL, SEG);
-    LdsScene ls = {nullptr, nullptr, make_bvh_stack(bvh_stk_lds, SEG)};
+    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, SEG)};
     if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
     if (DYN && ACCEL != ACCEL_K_BVH_LDS) __syncthreads();               // publishes the queue words
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];

@@ -8,22 +8,26 @@
 //            workgroup's queue -- the record of that ray was requested one refill earlier, so no lane waits on HBM -- and
 //            joins the two-phase walk of the others.  It reads 32 bytes per ray and writes 16 (hit) or 4 (visibility);
 //            nothing else is live, so two 1024-thread workgroups with their own image fit a CU (8 waves per SIMD).
-//   k_shade  per region: (1) adds the contributions of the previous bounce's unoccluded shadow rays to the radiance of their
-//            paths, in the fma order of the fused kernel; (2) ends the paths whose ray left the scene and lists the others;
-//            (3) shades the listed hits in full waves: emission + MIS, emitter sample -> shadow record, BSDF sample, Russian
-//            roulette; survivors and shadow records are packed to the front of the region (ballot + one LDS atomic per wave).
-// Same arithmetic per path, same RNG keys, same order of the radiance sums as bounce_step: the film does not change by a bit.
+//   k_shade  every wave on its own, no barrier after the set-up: it reads the hit records of its 64-slot chunks, ends the
+//            paths whose ray left the scene, keeps the slots of the others on a list of its own in LDS and shades 64 of them
+//            at a time with every lane busy: pending shadow contribution of the previous bounce, emission + MIS, emitter
+//            sample -> shadow record, BSDF sample, Russian roulette; survivors and shadow records are packed to the front of
+//            the region (ballot + one LDS atomic per wave).
+// The contribution of a shadow ray is added where the fused kernel added it -- L = fma(A, B, L) before the next bounce touches
+// L -- so the film does not change by a bit: same arithmetic per path, same RNG keys, same order of the radiance sums.
 //
-// Layouts (all float4 records, 64-byte path and shadow records so that a lane's gather is one or two 32-byte sectors):
-//   path state  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, home)  q3 = (L, -)
-//   hit         (t, u, v, primitive index | 0xffffffff: none)
-//   shadow ray  q0 = (origin, tmax; k_trace overwrites tmax by the visibility 1 / 0)  q1 = (direction, dest)  q2 = (A, -)  q3 = (B, -)
-//               the contribution is L = fma(A, B, L) per channel; dest = state slot of the survivor, or 0x80000000 | home
+// Layouts (float4 records):
+//   path state, 96 B  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, home)  q3 = (L, -)
+//                     q4 = (A, visibility of the path's shadow ray: written 0 by k_shade, set by k_trace)  q5 = (B, -)
+//   hit, 16 B         (t, u, v, primitive index | 0xffffffff: none)
+//   shadow ray, 64 B  q0 = (origin, tmax)  q1 = (direction, dest)  and, for paths that ended at the bounce that emitted it,
+//                     q2 = (A, visibility)  q3 = (B, home); dest = state slot of the survivor | WF_DEAD | own record index.
+//                     Rays of survivors fill a region's records from the front, rays of ended paths from the back.
 #pragma once
 #include "kernels_radiance.h"
 
 #define WF_REGION 4096u      // slots per region (compaction domain of k_shade)
-#define WF_KMAX 32u          // regions one k_trace workgroup walks at most
+#define WF_KMAX 21u          // regions one k_trace workgroup walks at most (three queue segments each)
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 16u    // idle lanes that make a wave fetch new rays
 #endif
@@ -33,18 +37,25 @@
 #ifndef WF_TRACE_WAVES_PER_EU
 #define WF_TRACE_WAVES_PER_EU 8
 #endif
+#ifndef WF_SHADE_THREADS
 #define WF_SHADE_THREADS 256u
-#define WF_DEAD 0x80000000u
+#endif
+#ifndef WF_SHADE_WAVES_PER_EU
+#define WF_SHADE_WAVES_PER_EU 5
+#endif
+#define WF_DEAD 0x40000000u   // shadow ray of a path that has ended: dest = WF_DEAD | index of the ray's own record
+#define WF_SHADOW 0x80000000u
+#define WF_STATE_Q 6u         // float4s per path-state record
 
 struct WfArgs {
     DevScene sc;
     pbrt_camera cam;
-    float4 *st_in, *st_out;      // [cap][4] path state
+    float4 *st_in, *st_out;      // [cap][6] path state
     float4 *hits;                // [cap]
     float4 *shd_in, *shd_out;    // [cap][4] shadow rays emitted by the previous / this bounce
     float *Lhome;                // [cap] float4 records (r, g, b, 0) indexed by home
-    const uint32_t *seg_in, *nsh_in;   // live paths / shadow rays of the previous bounce per region (nsh_in: nullptr at depth 0)
-    uint32_t *seg_out, *nsh_out;
+    const uint32_t *seg_in, *nsh_in;   // per region: live paths; shadow rays of the previous bounce (survivors' | ended paths' << 16)
+    uint32_t *seg_out, *nsh_out;       // (nsh_in: nullptr at depth 0)
     unsigned long long *stats;   // per-region rows as in RadArgs
     uint32_t stat_stride, cap, n_paths, n_regions;
     uint32_t depth, max_depth, rr_depth, seed;
@@ -52,7 +63,7 @@ struct WfArgs {
     FastDiv div_npix, div_rw;
     uint32_t index_offset, sample_index;
     uint32_t lds_bytes;          // ACCEL_K_BVH_LDS: bytes of the staged image
-    uint32_t stk_rows;           // rows of the traversal stacks behind the image (BvhStack::n_rows; one more row follows)
+    uint32_t stk_rows, stk_shift;  // traversal stacks behind the image: rows, log2(threads of the workgroup)
 };
 
 DEV RadArgs wf_key_args(const WfArgs &a) {  // path_key reads these members only
@@ -84,30 +95,37 @@ DEV void wf_camera_ray(const WfArgs &a, uint32_t home, V3 *o, V3 *d, float *tmax
 // Every loop of the stream has an exit that each wave reaches; the guard below is the net under it: a wave that exceeds
 // WF_GUARD_TURNS turns leaves, records its state in g_wf_guard and the host reports PBRT_E_DEVICE instead of hanging the box.
 #define WF_GUARD_TURNS (1u << 22)
-__device__ uint32_t g_wf_guard[16];  // [0] trips, [1..] state of the last wave that tripped
+__device__ uint32_t g_wf_guard[32];  // [0] trips, [1..] state of the last wave that tripped
 
 // ---- k_trace ---------------------------------------------------------------------------------------------------------------
 // grid: G workgroups; workgroup w walks the regions w, w + G, w + 2 G, ... (at most WF_KMAX of them) as ONE queue: for each of
-// its regions first the shadow rays, then the continuation rays.  dynamic LDS: [image | stack rows].
+// its regions the shadow rays of the survivors, those of the ended paths, then the continuation rays.
+// dynamic LDS: [image | stack rows].
 template <bool FIRST, int ACCEL>
 __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfArgs a) {
     static_assert(ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS, "k_trace: BVH scenes");
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t q_in;
-    __shared__ uint32_t cum[2 * WF_KMAX + 1];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, T = blockDim.x, G = gridDim.x;
+    __shared__ uint32_t cum[3 * WF_KMAX + 1];   // queue index at which a segment starts
+    __shared__ uint32_t seg0[3 * WF_KMAX];      // record index of a segment's first ray | WF_SHADOW | WF_DEAD
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, G = gridDim.x;
     const uint32_t K = (a.n_regions - blockIdx.x + G - 1u) / G;  // regions of this workgroup (host: <= WF_KMAX)
     if (tid == 0) {
         uint32_t run = 0;
         for (uint32_t j = 0; j < K; ++j) {
-            const uint32_t r = blockIdx.x + j * G;
-            cum[2 * j] = run;
-            run += (!FIRST && a.nsh_in) ? a.nsh_in[r] : 0u;
-            cum[2 * j + 1] = run;
-            const uint32_t b = r * WF_REGION;
+            const uint32_t r = blockIdx.x + j * G, b = r * WF_REGION;
+            const uint32_t ns = (!FIRST && a.nsh_in) ? a.nsh_in[r] : 0u;
+            cum[3 * j] = run;
+            seg0[3 * j] = b | WF_SHADOW;
+            run += ns & 0xffffu;
+            cum[3 * j + 1] = run;
+            seg0[3 * j + 1] = (b + WF_REGION - (ns >> 16)) | WF_SHADOW | WF_DEAD;
+            run += ns >> 16;
+            cum[3 * j + 2] = run;
+            seg0[3 * j + 2] = b;
             run += FIRST ? (a.n_paths > b ? min(a.n_paths - b, WF_REGION) : 0u) : a.seg_in[r];
         }
-        cum[2 * K] = run;
+        cum[3 * K] = run;
         q_in = 0;
     }
     LdsScene ls;
@@ -120,68 +138,118 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         ls.lprims = a.sc.lprims;
         __syncthreads();
     }
-    const BvhStack st = {stk_lds + tid, T, a.stk_rows};
-    const uint32_t total = cum[2 * K];
+    const BvhStack st = {stk_lds + tid, a.stk_shift, a.stk_rows};
+    const uint32_t total = cum[3 * K];
     if (total == 0) return;  // uniform
     const auto nodes = ls.nodes;
     const auto lprims = ls.lprims;
 
     bool busy = false, found = false;
-    uint32_t rslot = 0;  // slot of the ray's record | shadow ray << 31
+    uint32_t rslot = 0;  // closest hit: slot of the path | shadow ray: WF_SHADOW | dest (state slot, or WF_DEAD | record)
     V3 o = {0, 0, 0}, d = {0, 0, 1};
     BoxRay br = make_box_ray(o, d);
     float best = 0.0f, hu = 0.0f, hv = 0.0f;
     uint32_t hid = 0xffffffffu;
     BvhCursor c;
+    BvhOvf ovf;
     c.cur = BVH_SENT;
     c.tos = BVH_SENT;
     c.sp = 0;
-    // the record of the lane's NEXT ray, requested one refill ahead
-    bool has_next = false;
-    uint32_t n_slot = 0;
-    float4 n_q0 = {0, 0, 0, 0}, n_q1 = {0, 0, 1, 0};
     bool q_empty = false;   // wave-uniform
     uint32_t s_hint = 0;    // wave-uniform: segment of the wave's last fetch (queue indices only grow)
-    uint32_t turns = 0, visits = 0;
+    uint32_t turns = 0;  // wave-uniform: trips of the main loop + of the node walk
     for (;;) {
         if (++turns > WF_GUARD_TURNS) {
-            const unsigned long long bb = __ballot(busy), bi = __ballot(busy && (int32_t)c.cur >= 0), bn = __ballot(has_next);
+            const unsigned long long bb = __ballot(busy), bi = __ballot(busy && (int32_t)c.cur >= 0);
             if (lane == 0) {
                 atomicAdd(&g_wf_guard[0], 1u);
                 g_wf_guard[1] = blockIdx.x;
                 g_wf_guard[2] = tid >> 6;
                 g_wf_guard[3] = (uint32_t)__popcll(bb);
                 g_wf_guard[4] = (uint32_t)__popcll(bi);
-                g_wf_guard[5] = (uint32_t)__popcll(bn);
+                g_wf_guard[5] = 0;
                 g_wf_guard[6] = q_empty ? 1u : 0u;
                 g_wf_guard[7] = total;
                 g_wf_guard[8] = q_in;
-                g_wf_guard[9] = visits;
+                g_wf_guard[9] = 0;
                 g_wf_guard[10] = a.depth | (FIRST ? 0x100u : 0u);
                 g_wf_guard[11] = K;
+            }
+            {  // the first lane that is still walking: its cursor, stack and ray
+                const unsigned long long bwk = __ballot(busy && (int32_t)c.cur >= 0);
+                if (bwk && lane == (uint32_t)__builtin_ctzll(bwk)) {
+                    g_wf_guard[12] = c.cur;
+                    g_wf_guard[13] = c.sp;
+                    g_wf_guard[14] = c.tos;
+                    g_wf_guard[15] = rslot;
+                    g_wf_guard[16] = st.col[0];
+                    g_wf_guard[17] = st.col[1u << st.shift];
+                    g_wf_guard[18] = st.col[2u << st.shift];
+                    g_wf_guard[19] = ovf[0];
+                    g_wf_guard[20] = ovf[1];
+                    g_wf_guard[21] = __float_as_uint(o.x);
+                    g_wf_guard[22] = __float_as_uint(o.y);
+                    g_wf_guard[23] = __float_as_uint(o.z);
+                    g_wf_guard[24] = __float_as_uint(d.x);
+                    g_wf_guard[25] = __float_as_uint(d.y);
+                    g_wf_guard[26] = __float_as_uint(d.z);
+                    g_wf_guard[27] = __float_as_uint(best);
+                    g_wf_guard[28] = st.n_rows;
+                    g_wf_guard[29] = st.shift;
+                    g_wf_guard[30] = a.sc.n_nodes;
+                }
             }
             break;
         }
         // ---- retire
         if (busy && c.cur == BVH_SENT) {
-            if (rslot & 0x80000000u) {
-                reinterpret_cast<float *>(a.shd_in)[(size_t)(rslot & 0x7fffffffu) * 16u + 3u] = found ? 0.0f : 1.0f;
+            if (rslot & WF_SHADOW) {
+                const float vis = found ? 0.0f : 1.0f;
+                if (rslot & WF_DEAD)
+                    reinterpret_cast<float *>(a.shd_in)[(size_t)(rslot & 0x3fffffffu) * 16u + 11u] = vis;   // q2.w of the record
+                else
+                    reinterpret_cast<float *>(a.st_in)[(size_t)(rslot & 0x3fffffffu) * (WF_STATE_Q * 4u) + 19u] = vis;  // q4.w
             } else {
                 const float4 rec = {best, hu, hv, __uint_as_float(found ? hid : 0xffffffffu)};
                 a.hits[rslot] = rec;
             }
             busy = false;
         }
-        const uint32_t n_idle = (uint32_t)__popcll(__ballot(!busy));
-        // a refill helps only through rays that IDLE lanes can take: new queue entries, or their own prefetched records
-        const bool idle_next = !FIRST && __ballot(!busy && has_next) != 0;
-        if ((n_idle >= WF_REFILL_MIN || n_idle == 64u) && (!q_empty || idle_next)) {
-            if (!FIRST && !busy && has_next) {  // the prefetched record becomes the lane's ray
-                rslot = n_slot;
-                o = {n_q0.x, n_q0.y, n_q0.z};
-                d = {n_q1.x, n_q1.y, n_q1.z};
-                best = (rslot & 0x80000000u) ? n_q0.w : ((a.key_mode == 1 && a.depth == 0) ? n_q0.w : K_INF);
-                has_next = false;
+        // ---- idle lanes take the next rays of the queue.  (No prefetch of the records: at 8 waves per SIMD the stream is bound
+        // by VALU issue, the other waves cover the load, and the 9 registers of a record in flight would spill.)
+        const unsigned long long bw = __ballot(!busy);
+        const uint32_t nw = (uint32_t)__popcll(bw);
+        if (!q_empty && (nw >= WF_REFILL_MIN || nw == 64u)) {
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(&q_in, nw);
+            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            if (i0 + nw >= total) q_empty = true;
+            const uint32_t i = i0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
+            if (i0 < total) {
+                while (s_hint + 1u < 3u * K && i0 >= cum[s_hint + 1u]) ++s_hint;  // uniform
+            }
+            if (!busy && i < total) {
+                uint32_t s = s_hint;
+                while (i >= cum[s + 1u]) ++s;
+                const uint32_t first = seg0[s];
+                const uint32_t slot = (first & 0x3fffffffu) + (i - cum[s]);
+                if (FIRST) {
+                    uint32_t ka, kb;
+                    wf_camera_ray(a, slot, &o, &d, &best, &ka, &kb);
+                    rslot = slot;
+                } else {
+                    const float4 *rec = (first & WF_SHADOW) ? a.shd_in + (size_t)slot * 4u : a.st_in + (size_t)slot * WF_STATE_Q;
+                    const float4 q0 = rec[0], q1 = rec[1];
+                    o = {q0.x, q0.y, q0.z};
+                    d = {q1.x, q1.y, q1.z};
+                    if (first & WF_SHADOW) {
+                        best = q0.w;
+                        rslot = WF_SHADOW | __float_as_uint(q1.w);  // where the visibility goes
+                    } else {
+                        best = (a.key_mode == 1 && a.depth == 0) ? q0.w : K_INF;  // caller rays carry tmax in the eta slot
+                        rslot = slot;
+                    }
+                }
                 busy = true;
                 found = false;
                 br = make_box_ray(o, d);
@@ -189,52 +257,9 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                 c.tos = BVH_SENT;
                 c.sp = 0;
             }
-            if (!q_empty) {
-                const bool want = FIRST ? !busy : !has_next;
-                const unsigned long long bw = __ballot(want);
-                const uint32_t nw = (uint32_t)__popcll(bw);
-                if (nw) {
-                    uint32_t got = 0;
-                    if (lane == 0) got = atomicAdd(&q_in, nw);
-                    const uint32_t i0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                    if (i0 + nw >= total) q_empty = true;
-                    const uint32_t i = i0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(bw >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bw, 0u));
-                    if (i0 < total) {
-                        while (s_hint + 1u < 2u * K && i0 >= cum[s_hint + 1u]) ++s_hint;  // uniform
-                    }
-                    if (want && i < total) {
-                        uint32_t s = s_hint;
-                        while (i >= cum[s + 1u]) ++s;
-                        const uint32_t r = blockIdx.x + (s >> 1) * G;
-                        const uint32_t slot = r * WF_REGION + (i - cum[s]);
-                        const bool shadow = !(s & 1u);
-                        if (FIRST) {
-                            uint32_t ka, kb;
-                            float tm;
-                            wf_camera_ray(a, slot, &o, &d, &tm, &ka, &kb);
-                            rslot = slot;
-                            best = tm;
-                            busy = true;
-                            found = false;
-                            br = make_box_ray(o, d);
-                            c.cur = 0;
-                            c.tos = BVH_SENT;
-                            c.sp = 0;
-                        } else {
-                            const float4 *rec = (shadow ? a.shd_in : a.st_in) + (size_t)slot * 4u;
-                            n_q0 = rec[0];
-                            n_q1 = rec[1];
-                            n_slot = slot | (shadow ? 0x80000000u : 0u);
-                            has_next = true;
-                        }
-                    }
-                }
-            }
         }
         if (__ballot(busy) == 0) {
-            if (FIRST || __ballot(has_next) == 0) {
-                if (q_empty) break;
-            }
+            if (q_empty) break;
             continue;
         }
         // ---- one turn of the walk: inner nodes until every busy lane holds a leaf or has finished (or, while new rays can be
@@ -242,15 +267,12 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         const bool can_refill = !q_empty;  // wave-uniform (a prefetched record only serves its own lane, once that lane is idle)
         while (busy && (int32_t)c.cur >= 0) {
             if (can_refill && (uint32_t)__popcll(__ballot(true)) < WF_WALK_MIN) break;
-            if (++visits > WF_GUARD_TURNS) {  // (the main loop's guard reports)
-                turns = WF_GUARD_TURNS;
-                break;
-            }
-            bvh_visit(nodes, st, c, br, best);
+            if (++turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
+            bvh_visit(nodes, st, c, ovf, br, best);
         }
         if (busy && (int32_t)c.cur < 0 && c.cur != BVH_SENT) {
             const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
-            const bool any = (rslot & 0x80000000u) != 0u;
+            const bool any = (rslot & WF_SHADOW) != 0u;
             bool stop = false;
             for (uint32_t k = 0; k < count && !stop; ++k) {
                 float t, u, v;
@@ -268,8 +290,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                     }
                 }
             }
-            c.cur = bvh_pop(st, c);
-            if (stop) c.cur = BVH_SENT;
+            c.cur = stop ? BVH_SENT : bvh_pop(nodes, st, c, ovf);
         }
     }
 }
@@ -354,16 +375,45 @@ DEV bool wf_shade_step(const WfArgs &a, const Tables &tb, uint32_t depth, uint32
     return survive;
 }
 
-template <bool FIRST, int ACCEL>
-__global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
+// LDS copies of the small shading tables of a BVH scene (materials, emitters, and the records of the LIGHT primitives only:
+// the table of all primitives stays in global memory and is read once per hit).  Layout [light prims | mats | emitters | cdf];
+// light_prims becomes the identity, so sample_emitter runs unchanged.  Used when every table has <= TAB_MAX entries.
+#define WF_TAB_DW (TAB_MAX * 16 + TAB_MAX * 8 + TAB_MAX * 12 + TAB_MAX + TAB_MAX)
+DEV Tables wf_tables_lds(const DevScene &sc, uint32_t *lds, uint32_t n_threads) {
+    uint32_t *p_prims = lds, *p_mats = lds + TAB_MAX * 16, *p_emit = p_mats + TAB_MAX * 8, *p_lp = p_emit + TAB_MAX * 12;
+    float *p_lc = reinterpret_cast<float *>(p_lp + TAB_MAX);
+    for (uint32_t t = threadIdx.x; t < TAB_MAX * 16; t += n_threads) {
+        if (t < sc.n_light_prims * 16) p_prims[t] = reinterpret_cast<const uint32_t *>(sc.prims_by_id + sc.light_prims[t >> 4])[t & 15u];
+        if (t < sc.n_mats * 8) p_mats[t] = reinterpret_cast<const uint32_t *>(sc.mats)[t];
+        if (t < sc.n_emitters * 12) p_emit[t] = reinterpret_cast<const uint32_t *>(sc.emitters)[t];
+        if (t < sc.n_light_prims) {
+            p_lp[t] = t;
+            p_lc[t] = sc.light_cdf[t];
+        }
+    }
+    Tables tb;
+    tb.prims_by_slot = sc.prims;  // the primitive that was hit: global memory
+    tb.prims_by_id = reinterpret_cast<const pbrt_prim *>(p_prims);
+    tb.mats = reinterpret_cast<const pbrt_material *>(p_mats);
+    tb.emitters = reinterpret_cast<const pbrt_emitter *>(p_emit);
+    tb.light_prims = p_lp;
+    tb.light_cdf = p_lc;
+    tb.n_emitters = sc.n_emitters;
+    return tb;
+}
+
+// TABS: the small tables fit LDS (wf_tables_lds), else everything is read from global memory
+template <bool FIRST, bool TABS>
+__global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_shade(const WfArgs a) {
     constexpr uint32_t T = WF_SHADE_THREADS, W = T / 64;
-    __shared__ uint32_t hit_list[WF_REGION];
-    __shared__ uint32_t n_hit, q_out, q_shd;
+    __shared__ uint32_t wlist[W][128];  // per wave: slots (within the region) of paths that hit something and wait for a full wave
+    __shared__ uint32_t q_out, q_shd, q_dead, q_done;
+    __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
     const uint32_t r = xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, WF_REGION) : 0u) : a.seg_in[r];
-    const uint32_t n_shd = (!FIRST && a.nsh_in) ? a.nsh_in[r] : 0u;
-    if (cnt_in == 0 && n_shd == 0) {  // uniform
+    const uint32_t n_dead = (!FIRST && a.nsh_in) ? a.nsh_in[r] >> 16 : 0u;
+    if (cnt_in == 0 && n_dead == 0) {  // uniform
         if (tid == 0) {
             a.seg_out[r] = 0;
             a.nsh_out[r] = 0;
@@ -371,19 +421,20 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
         return;
     }
     if (tid == 0) {
-        n_hit = 0;
         q_out = 0;
         q_shd = 0;
+        q_dead = 0;
+        q_done = 0;
     }
+    const Tables tb = TABS ? wf_tables_lds(a.sc, tab_lds, T) : global_tables(a.sc);
+    __syncthreads();  // the only barrier
     float4 *Lh = reinterpret_cast<float4 *>(a.Lhome);
-    // ---- (1) the unoccluded shadow rays of the previous bounce: L = fma(A, B, L) on the path's radiance
-    for (uint32_t k = tid; k < n_shd; k += T) {
-        const float4 *rec = a.shd_in + (size_t)(base + k) * 4u;
-        const float4 q0 = rec[0];
-        if (q0.w != 0.0f) {
-            const float4 q1 = rec[1], A = rec[2], B = rec[3];
-            const uint32_t dest = __float_as_uint(q1.w);
-            float4 *Lp = (dest & WF_DEAD) ? Lh + (dest & 0x7fffffffu) : a.st_in + (size_t)dest * 4u + 3u;
+    // ---- shadow rays of paths that ended at the previous bounce: L = fma(A, B, L) on the radiance record
+    for (uint32_t k = tid; k < n_dead; k += T) {
+        const float4 *rec = a.shd_in + (size_t)(base + WF_REGION - n_dead + k) * 4u;
+        const float4 A = rec[2], B = rec[3];
+        if (A.w != 0.0f) {
+            float4 *Lp = Lh + __float_as_uint(B.w);
             float4 Lv = *Lp;
             Lv.x = fma_(A.x, B.x, Lv.x);
             Lv.y = fma_(A.y, B.y, Lv.y);
@@ -391,45 +442,48 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
             *Lp = Lv;
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---- (2) paths whose ray left the scene end here; the others are listed
-    for (uint32_t s0 = 0; s0 < cnt_in; s0 += T) {
-        const uint32_t s = s0 + tid;
-        const bool valid = s < cnt_in;
-        bool is_hit = false;
-        if (valid) {
-            const uint32_t id = __float_as_uint(a.hits[base + s].w);
-            is_hit = id != 0xffffffffu;
-            if (!is_hit) {
-                if (FIRST) {
-                    const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                    Lh[base + s] = z;
-                } else {
-                    const float4 *stp = a.st_in + (size_t)(base + s) * 4u;
-                    const uint32_t home = __float_as_uint(stp[2].w);
-                    float4 Lv = stp[3];
-                    Lv.w = 0.0f;
-                    Lh[home] = Lv;
+    uint32_t list_n = 0;             // wave-uniform: entries on this wave's list
+    uint32_t n_seg_w = 0, n_shd_w = 0;
+    uint32_t c0 = wid * 64u;         // the wave's next chunk of the region
+    for (;;) {
+        if (c0 < cnt_in) {
+            // ---- a chunk of hit records: paths whose ray left the scene end here, the others go on the list
+            const uint32_t s = c0 + lane;
+            bool is_hit = false;
+            if (s < cnt_in) {
+                const uint32_t id = __float_as_uint(a.hits[base + s].w);
+                is_hit = id != 0xffffffffu;
+                if (!is_hit) {
+                    if (FIRST) {
+                        const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+                        Lh[base + s] = z;
+                    } else {
+                        const float4 *stp = a.st_in + (size_t)(base + s) * WF_STATE_Q;
+                        const float4 q2 = stp[2], q4 = stp[4], q5 = stp[5];
+                        float4 Lv = stp[3];
+                        if (q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
+                            Lv.x = fma_(q4.x, q5.x, Lv.x);
+                            Lv.y = fma_(q4.y, q5.y, Lv.y);
+                            Lv.z = fma_(q4.z, q5.z, Lv.z);
+                        }
+                        Lv.w = 0.0f;
+                        Lh[__float_as_uint(q2.w)] = Lv;
+                    }
                 }
             }
+            const unsigned long long bh = __ballot(is_hit);
+            if (is_hit) wlist[wid][list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u))] = s;
+            __builtin_amdgcn_wave_barrier();  // other lanes of the wave read these entries below (LDS operations of a wave stay in order)
+            list_n += (uint32_t)__popcll(bh);
+            c0 += W * 64u;
+        } else if (list_n == 0) {
+            break;
         }
-        const unsigned long long bh = __ballot(is_hit);
-        if (bh) {
-            uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(&n_hit, (uint32_t)__popcll(bh));
-            const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            if (is_hit) hit_list[off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u))] = s;
-        }
-    }
-    __syncthreads();
-    const uint32_t nh = n_hit;
-    const Tables tb = global_tables(a.sc);
-    uint32_t n_shadow_w = 0;
-    // ---- (3) the listed hits, in full waves
-    for (uint32_t e0 = 0; e0 < nh; e0 += T) {
-        const uint32_t e = e0 + tid;
-        const bool act = e < nh;
+        if (list_n < 64u && c0 < cnt_in) continue;
+        // ---- shade 64 listed paths (or what is left at the end) with every lane busy
+        const uint32_t take = min(list_n, 64u);
+        const bool act = lane < take;
+        list_n -= take;
         bool survive = false;
         WfShadow sh;
         sh.on = false;
@@ -437,7 +491,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
         float eta = 1.0f, prev_pdf = -1.0f;
         uint32_t home = 0;
         if (act) {
-            const uint32_t s = hit_list[e];
+            const uint32_t s = wlist[wid][list_n + lane];
             const float4 hr = a.hits[base + s];
             Hit h;
             h.t = hr.x;
@@ -451,12 +505,13 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
                 home = base + s;
                 wf_camera_ray(a, home, &o, &d, &tm, &ka, &kb);
             } else {
-                const float4 *stp = a.st_in + (size_t)(base + s) * 4u;
-                const float4 q0 = stp[0], q1 = stp[1], q2 = stp[2], q3 = stp[3];
+                const float4 *stp = a.st_in + (size_t)(base + s) * WF_STATE_Q;
+                const float4 q0 = stp[0], q1 = stp[1], q2 = stp[2], q3 = stp[3], q4 = stp[4], q5 = stp[5];
                 o = {q0.x, q0.y, q0.z};
                 d = {q1.x, q1.y, q1.z};
                 thr = {q2.x, q2.y, q2.z};
                 L = {q3.x, q3.y, q3.z};
+                if (q4.w != 0.0f) L = {fma_(q4.x, q5.x, L.x), fma_(q4.y, q5.y, L.y), fma_(q4.z, q5.z, L.z)};
                 eta = (a.key_mode == 1 && a.depth == 0) ? 1.0f : q0.w;  // caller rays carry tmax in the eta slot
                 prev_pdf = q1.w;
                 home = __float_as_uint(q2.w);
@@ -464,41 +519,62 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);
             }
-            survive = wf_shade_step<ACCEL>(a, tb, a.depth, ka, kb, h, o, d, thr, L, eta, prev_pdf, sh);
+            survive = wf_shade_step<ACCEL_K_BVH_GLOBAL>(a, tb, a.depth, ka, kb, h, o, d, thr, L, eta, prev_pdf, sh);
         }
+        n_seg_w += take;
         // survivors -> front of the region of the `out` state
         const unsigned long long bs = __ballot(survive);
         uint32_t out_slot = 0;
-        {
+        if (bs) {
             uint32_t got = 0;
-            if (lane == 0 && bs) got = atomicAdd(&q_out, (uint32_t)__popcll(bs));
+            if (lane == 0) got = atomicAdd(&q_out, (uint32_t)__popcll(bs));
             const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
             out_slot = base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs, 0u));
         }
+        const bool shd_live = sh.on && survive, shd_dead = sh.on && !survive;
         if (survive) {
-            float4 *stp = a.st_out + (size_t)out_slot * 4u;
+            float4 *stp = a.st_out + (size_t)out_slot * WF_STATE_Q;
             const float4 q0 = {o.x, o.y, o.z, eta}, q1 = {d.x, d.y, d.z, prev_pdf}, q2 = {thr.x, thr.y, thr.z, __uint_as_float(home)},
                          q3 = {L.x, L.y, L.z, 0.0f};
             stp[0] = q0;
             stp[1] = q1;
             stp[2] = q2;
             stp[3] = q3;
-        } else if (act) {  // the path ends (its pending shadow ray, if any, is added to this record by the next k_shade)
+            const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            const float4 q4 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q5 = {sh.B.x, sh.B.y, sh.B.z, 0.0f};
+            stp[4] = shd_live ? q4 : z;
+            stp[5] = shd_live ? q5 : z;
+        } else if (act) {  // the path ends (a pending shadow ray is added to this record by the next k_shade)
             const float4 rec = {L.x, L.y, L.z, 0.0f};
             Lh[home] = rec;
         }
-        const unsigned long long bsh = __ballot(sh.on);
-        if (bsh) {
+        const unsigned long long bl = __ballot(shd_live);
+        if (bl) {
             uint32_t got = 0;
-            if (lane == 0) got = atomicAdd(&q_shd, (uint32_t)__popcll(bsh));
+            if (lane == 0) got = atomicAdd(&q_shd, (uint32_t)__popcll(bl));
             const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-            n_shadow_w += (uint32_t)__popcll(bsh);
-            if (sh.on) {
-                const uint32_t k = base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bsh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bsh, 0u));
+            n_shd_w += (uint32_t)__popcll(bl);
+            if (shd_live) {
+                const uint32_t k = base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+                float4 *rec = a.shd_out + (size_t)k * 4u;
+                const float4 q0 = {sh.so.x, sh.so.y, sh.so.z, sh.tmax}, q1 = {sh.sdir.x, sh.sdir.y, sh.sdir.z, __uint_as_float(out_slot)};
+                rec[0] = q0;
+                rec[1] = q1;
+            }
+        }
+        const unsigned long long bd = __ballot(shd_dead);
+        if (bd) {  // rare: Russian roulette ended a path that had just sent a shadow ray
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(&q_dead, (uint32_t)__popcll(bd));
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            n_shd_w += (uint32_t)__popcll(bd);
+            if (shd_dead) {
+                const uint32_t k =
+                    base + WF_REGION - 1u - (off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bd, 0u)));
                 float4 *rec = a.shd_out + (size_t)k * 4u;
                 const float4 q0 = {sh.so.x, sh.so.y, sh.so.z, sh.tmax},
-                             q1 = {sh.sdir.x, sh.sdir.y, sh.sdir.z, __uint_as_float(survive ? out_slot : (WF_DEAD | home))},
-                             q2 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q3 = {sh.B.x, sh.B.y, sh.B.z, 0.0f};
+                             q1 = {sh.sdir.x, sh.sdir.y, sh.sdir.z, __uint_as_float(WF_DEAD | k)},
+                             q2 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q3 = {sh.B.x, sh.B.y, sh.B.z, __uint_as_float(home)};
                 rec[0] = q0;
                 rec[1] = q1;
                 rec[2] = q2;
@@ -506,19 +582,19 @@ __global__ __launch_bounds__(WF_SHADE_THREADS) void k_shade(const WfArgs a) {
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) {
-        a.seg_out[r] = q_out;
-        a.nsh_out[r] = q_shd;
-        unsigned long long *row = a.stats + r;
+    if (lane == 0) {
+        unsigned long long *row = a.stats + (size_t)r * W + wid;  // per-wave statistics rows
         const size_t stride = a.stat_stride;
-        row[0] += nh;
-        row[stride] += q_shd;
-        row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
-        row[(HIT_ROW0 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += nh;  // hits of this depth (byte model)
+        row[0] += n_seg_w;
+        row[stride] += n_shd_w;
+        row[(HIT_ROW0 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += n_seg_w;  // hits of this depth (byte model)
+        if (wid == 0) row[(2 + min(a.depth, (uint32_t)MAX_DEPTH_STATS - 1)) * stride] += cnt_in;
+        // the last wave to finish publishes the region's counts (LDS atomics of one CU are ordered)
+        if (atomicAdd(&q_done, 1u) == W - 1) {
+            a.seg_out[r] = atomicAdd(&q_out, 0u);
+            a.nsh_out[r] = atomicAdd(&q_shd, 0u) | (atomicAdd(&q_dead, 0u) << 16);
+        }
     }
-    (void)n_shadow_w;
-    (void)W;
 }
 
 // upload of caller rays for Integrator.sample(): o, d [3][n] SoA + tmax -> path-state records (tmax rides in the eta slot)
@@ -527,11 +603,13 @@ __global__ __launch_bounds__(256) void k_init_rays_wf(float4 *st, uint32_t *seg_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_regions) seg_cnt[i] = n > i * WF_REGION ? min(n - i * WF_REGION, WF_REGION) : 0u;
     if (i >= n) return;
-    float4 *s = st + (size_t)i * 4u;
+    float4 *s = st + (size_t)i * WF_STATE_Q;
     const float4 q0 = {o[i], o[n + i], o[2 * n + i], tmax[i]}, q1 = {d[i], d[n + i], d[2 * n + i], -1.0f},
                  q2 = {1.0f, 1.0f, 1.0f, __uint_as_float(i)}, q3 = {0.0f, 0.0f, 0.0f, 0.0f};
     s[0] = q0;
     s[1] = q1;
     s[2] = q2;
     s[3] = q3;
+    s[4] = q3;
+    s[5] = q3;
 }

@@ -35,7 +35,7 @@ struct pbrt_ctx {
     uint32_t lds_limit = 0;
 
     int fail(int code, const char *fmt, ...) {
-        char buf[512];
+        char buf[1024];
         va_list ap;
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
@@ -362,8 +362,8 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         build_bvh(d->prims, d->n_prims, &bvh);
         HostBvh4 b4;
         to_bvh4(bvh, &b4);
-        // traversal stack: at most three entries per level of inner nodes (device_scene.h BvhStack)
-        if (3u * b4.depth + 1u > BVH_STK_MAX || b4.nodes.size() >= (1u << 31) || d->n_prims >= (1u << 27)) {
+        // traversal stack: one entry per level of inner nodes, 24-bit node indices (device_scene.h BvhStack)
+        if (b4.depth > BVH_STK_MAX || b4.nodes.size() >= (1u << 24) - 1u || d->n_prims >= (1u << 27)) {
             pbrt_scene_destroy(s);
             return c->fail(PBRT_E_UNSUPPORTED, "BVH depth %u / %zu nodes exceed the traversal state", b4.depth, b4.nodes.size());
         }
@@ -545,15 +545,18 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     const uint32_t limit = s->ctx->lds_limit ? s->ctx->lds_limit : 65536u;
     const uint32_t image = s->accel_kernel == ACCEL_K_BVH_LDS ? s->lds_bytes : 0u;
     p.threads = image ? 1024u : 256u;
-    if (e_thr) p.threads = std::min(1024u, std::max(64u, (uint32_t)atoi(e_thr) & ~63u));
+    if (e_thr) {  // a power of two (the stack rows are addressed by a shift)
+        const uint32_t want = (uint32_t)atoi(e_thr);
+        p.threads = want >= 1024u ? 1024u : want >= 512u ? 512u : want >= 256u ? 256u : want >= 128u ? 128u : 64u;
+    }
     const uint32_t statics = 1024;  // queue words and the segment table, with slack
     uint32_t budget = limit / 2;     // two workgroups per CU
     if (image + statics + 3u * p.threads * 4u > budget) budget = limit;
-    uint32_t rows_total = (budget - image - statics) / (p.threads * 4u);
-    p.rows = std::max(2u, std::min(rows_total - 1u, 8u));
+    const uint32_t rows_fit = (budget - image - statics) / (p.threads * 4u);
+    p.rows = std::max(2u, std::min(rows_fit, 8u));
     if (e_rows) p.rows = std::max(2u, std::min((uint32_t)atoi(e_rows), 15u));
     if (e_grid) p.grid_mult = std::max(1u, (uint32_t)atoi(e_grid));
-    p.lds = (size_t)image + (size_t)(p.rows + 1u) * p.threads * 4u;
+    p.lds = (size_t)image + (size_t)p.rows * p.threads * 4u;
     return p;
 }
 static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
@@ -571,8 +574,8 @@ struct WfBufs {
     uint32_t *segA, *segB, *nshA, *nshB;
 };
 static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
-    b->stA = (float4 *)c->buf("wf_stateA", (size_t)cap * 64);
-    b->stB = (float4 *)c->buf("wf_stateB", (size_t)cap * 64);
+    b->stA = (float4 *)c->buf("wf_stateA", (size_t)cap * WF_STATE_Q * 16);
+    b->stB = (float4 *)c->buf("wf_stateB", (size_t)cap * WF_STATE_Q * 16);
     b->hits = (float4 *)c->buf("wf_hits", (size_t)cap * 16);
     b->shA = (float4 *)c->buf("wf_shadowA", (size_t)cap * 64);
     b->shB = (float4 *)c->buf("wf_shadowB", (size_t)cap * 64);
@@ -592,6 +595,10 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     a.n_regions = nreg;
     a.lds_bytes = lds ? s->lds_bytes : 0u;
     a.stk_rows = p.rows;
+    a.stk_shift = 0;
+    while ((1u << a.stk_shift) < p.threads) ++a.stk_shift;
+    // the small shading tables in LDS when they fit (kernels_wavefront.h wf_tables_lds)
+    const bool tabs = s->ds.n_mats <= TAB_MAX && s->ds.n_emitters <= TAB_MAX && s->ds.n_light_prims <= TAB_MAX;
     float4 *in = b.stA, *out = b.stB, *shi = b.shA, *sho = b.shB;
     uint32_t *sin = b.segA, *sout = b.segB, *ni = b.nshA, *no = b.nshB;
     auto one = [&](uint32_t depth, bool first, bool have_shadows) {
@@ -610,13 +617,19 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
             else
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
-            hipLaunchKernelGGL((k_shade<true, ACCEL_K_BVH_GLOBAL>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+            if (tabs)
+                hipLaunchKernelGGL((k_shade<true, true>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_shade<true, false>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
         } else {
             if (lds)
                 hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
             else
                 hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
-            hipLaunchKernelGGL((k_shade<false, ACCEL_K_BVH_GLOBAL>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+            if (tabs)
+                hipLaunchKernelGGL((k_shade<false, true>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
+            else
+                hipLaunchKernelGGL((k_shade<false, false>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
         }
         *launches += 2;
         std::swap(in, out);
@@ -650,15 +663,19 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
 }
 // after the stream has drained: did a wave of k_trace run into its turn guard?
 static int wf_check_guard(pbrt_ctx *c) {
-    uint32_t g[16];
+    uint32_t g[32];
     HIPCHK(c, hipMemcpyFromSymbol(g, HIP_SYMBOL(g_wf_guard), sizeof g));
     if (g[0] == 0) return PBRT_OK;
-    const uint32_t z[16] = {0};
+    const uint32_t z[32] = {0};
     HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wf_guard), z, sizeof z));
+    float f[7];
+    std::memcpy(f, g + 21, sizeof f);
     return c->fail(PBRT_E_DEVICE,
-                   "k_trace: %u wave(s) hit the turn guard (block %u wave %u: busy %u walking %u prefetched %u queue_empty %u total %u "
-                   "q_in %u visits %u depth 0x%x K %u)",
-                   g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7], g[8], g[9], g[10], g[11]);
+                   "k_trace: %u wave(s) hit the turn guard (block %u wave %u: busy %u walking %u queue_empty %u total %u q_in %u visits %u "
+                   "depth 0x%x K %u | lane: cur %x sp %u tos %x rslot %x rows %x %x %x ovf %x %x o %g %g %g d %g %g %g best %g n_rows %u "
+                   "shift %u nodes %u)",
+                   g[0], g[1], g[2], g[3], g[4], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[15], g[16], g[17], g[18],
+                   g[19], g[20], f[0], f[1], f[2], f[3], f[4], f[5], f[6], g[28], g[29], g[30]);
 }
 
 // Byte model of the two-launch bounce: k_trace reads 32 B per ray and writes a 16-B hit or a 4-B visibility;
@@ -716,7 +733,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     WfBufs wfb{};
     WfPlan wfp;
     if (wavefront) {
-        NEED(c, cap < 0x80000000u);  // shadow records address a home with bit 31 as the flag
+        NEED(c, cap < WF_DEAD);  // ray records are addressed with two flag bits on top
         if (!wf_alloc(c, cap, nseg, &wfb)) return PBRT_E_NOMEM;
         wfp = wf_plan(s);
         if ((rc = wf_set_attr(s, wfp)) != 0) return rc;
@@ -736,7 +753,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t *quota = repack ? (uint32_t *)c->buf("seg_quota", 64) : nullptr;
     float *acc = (float *)c->buf("film_acc", film_px * 16);
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + 2 * MAX_DEPTH_STATS) * 8);
-    const uint32_t n_rows = nseg * (wavefront ? 1u : rad_rows_per_region(s->accel_kernel));  // statistics rows
+    const uint32_t n_rows = nseg * (wavefront ? WF_SHADE_THREADS / 64u : rad_rows_per_region(s->accel_kernel));  // statistics rows
     // statistics rows in use: segments, shadow rays, one per depth (cleared and reduced per call: keep it to what the call touches)
     const uint32_t stat_rows = 2 + (uint32_t)std::min<uint64_t>(f->max_depth, MAX_DEPTH_STATS);
     const size_t segstats_bytes = (size_t)stat_rows * n_rows * 8;  // reduced at the end
@@ -1068,20 +1085,21 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
     if (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) {  // trace / shade streams
-        NEED(c, cap < 0x80000000u);
+        NEED(c, cap < WF_DEAD);
         WfBufs b{};
         if (!wf_alloc(c, cap, nseg, &b)) return PBRT_E_NOMEM;
         const WfPlan p = wf_plan(s);
         if ((rc = wf_set_attr(s, p)) != 0) return rc;
         float *Lh = (float *)c->buf("Lhome", (size_t)cap * 16);
-        unsigned long long *rows = (unsigned long long *)c->buf("segstats", (size_t)(2 + 2 * MAX_DEPTH_STATS) * nseg * 8);
+        const uint32_t n_rows = nseg * (WF_SHADE_THREADS / 64u);
+        unsigned long long *rows = (unsigned long long *)c->buf("segstats", (size_t)(2 + 2 * MAX_DEPTH_STATS) * n_rows * 8);
         float *io = (float *)c->buf("leaf_io", (size_t)n * 7 * 4);
         if (!Lh || !rows || !io) return PBRT_E_NOMEM;
         hipStream_t st = c->stream;
         HIPCHK(c, hipMemcpyAsync(io, o, (size_t)n * 12, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(io + 3 * (size_t)n, d, (size_t)n * 12, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
-        HIPCHK(c, hipMemsetAsync(rows, 0, (size_t)(2 + 2 * MAX_DEPTH_STATS) * nseg * 8, st));
+        HIPCHK(c, hipMemsetAsync(rows, 0, (size_t)(2 + 2 * MAX_DEPTH_STATS) * n_rows * 8, st));
         HIPCHK(c, hipMemsetAsync(Lh, 0, (size_t)cap * 16, st));
         hipLaunchKernelGGL(k_init_rays_wf, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, b.stA, b.segA, nseg, n, io,
                            io + 3 * (size_t)n, io + 6 * (size_t)n);
@@ -1089,7 +1107,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         w.sc = s->ds;
         w.Lhome = Lh;
         w.stats = rows;
-        w.stat_stride = nseg;
+        w.stat_stride = n_rows;
         w.cap = cap;
         w.n_paths = n;
         w.max_depth = max_depth;

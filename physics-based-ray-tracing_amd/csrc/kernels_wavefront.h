@@ -16,7 +16,9 @@
 // The contribution of a shadow ray is added where the fused kernel added it -- L = fma(A, B, L) before the next bounce touches
 // L -- so the film does not change by a bit: same arithmetic per path, same RNG keys, same order of the radiance sums.
 //
-// Layouts (float4 records):
+// Layouts: float4 PLANES -- component q of record i at base[q * cap + i] -- so that the streaming accesses (a wave writes the
+// survivors it packed, reads the rays of consecutive queue entries, ends the missed paths of a chunk) are 1 KiB contiguous per
+// wave-instruction; only the state of the paths that hit something is gathered:
 //   path state, 96 B  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, home)  q3 = (L, -)
 //                     q4 = (A, visibility of the path's shadow ray: written 0 by k_shade, set by k_trace)  q5 = (B, -)
 //   hit, 16 B         (t, u, v, primitive index | 0xffffffff: none)
@@ -206,9 +208,9 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             if (rslot & WF_SHADOW) {
                 const float vis = found ? 0.0f : 1.0f;
                 if (rslot & WF_DEAD)
-                    reinterpret_cast<float *>(a.shd_in)[(size_t)(rslot & 0x3fffffffu) * 16u + 11u] = vis;   // q2.w of the record
+                    reinterpret_cast<float *>(a.shd_in + 2u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;  // q2.w of the record
                 else
-                    reinterpret_cast<float *>(a.st_in)[(size_t)(rslot & 0x3fffffffu) * (WF_STATE_Q * 4u) + 19u] = vis;  // q4.w
+                    reinterpret_cast<float *>(a.st_in + 4u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // q4.w of the state
             } else {
                 const float4 rec = {best, hu, hv, __uint_as_float(found ? hid : 0xffffffffu)};
                 a.hits[rslot] = rec;
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                     wf_camera_ray(a, slot, &o, &d, &best, &ka, &kb);
                     rslot = slot;
                 } else {
-                    const float4 *rec = (first & WF_SHADOW) ? a.shd_in + (size_t)slot * 4u : a.st_in + (size_t)slot * WF_STATE_Q;
-                    const float4 q0 = rec[0], q1 = rec[1];
+                    const float4 *rec = ((first & WF_SHADOW) ? a.shd_in : a.st_in) + slot;
+                    const float4 q0 = rec[0], q1 = rec[a.cap];
                     o = {q0.x, q0.y, q0.z};
                     d = {q1.x, q1.y, q1.z};
                     if (first & WF_SHADOW) {
@@ -431,8 +433,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
     float4 *Lh = reinterpret_cast<float4 *>(a.Lhome);
     // ---- shadow rays of paths that ended at the previous bounce: L = fma(A, B, L) on the radiance record
     for (uint32_t k = tid; k < n_dead; k += T) {
-        const float4 *rec = a.shd_in + (size_t)(base + WF_REGION - n_dead + k) * 4u;
-        const float4 A = rec[2], B = rec[3];
+        const float4 *rec = a.shd_in + (base + WF_REGION - n_dead + k);
+        const float4 A = rec[2u * (size_t)a.cap], B = rec[3u * (size_t)a.cap];
         if (A.w != 0.0f) {
             float4 *Lp = Lh + __float_as_uint(B.w);
             float4 Lv = *Lp;
@@ -458,9 +460,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                         const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
                         Lh[base + s] = z;
                     } else {
-                        const float4 *stp = a.st_in + (size_t)(base + s) * WF_STATE_Q;
-                        const float4 q2 = stp[2], q4 = stp[4], q5 = stp[5];
-                        float4 Lv = stp[3];
+                        const float4 *stp = a.st_in + (base + s);
+                        const size_t cp = a.cap;
+                        const float4 q2 = stp[2u * cp], q4 = stp[4u * cp], q5 = stp[5u * cp];
+                        float4 Lv = stp[3u * cp];
                         if (q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
                             Lv.x = fma_(q4.x, q5.x, Lv.x);
                             Lv.y = fma_(q4.y, q5.y, Lv.y);
@@ -505,8 +508,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 home = base + s;
                 wf_camera_ray(a, home, &o, &d, &tm, &ka, &kb);
             } else {
-                const float4 *stp = a.st_in + (size_t)(base + s) * WF_STATE_Q;
-                const float4 q0 = stp[0], q1 = stp[1], q2 = stp[2], q3 = stp[3], q4 = stp[4], q5 = stp[5];
+                const float4 *stp = a.st_in + (base + s);
+                const size_t cp = a.cap;
+                const float4 q0 = stp[0], q1 = stp[cp], q2 = stp[2u * cp], q3 = stp[3u * cp], q4 = stp[4u * cp], q5 = stp[5u * cp];
                 o = {q0.x, q0.y, q0.z};
                 d = {q1.x, q1.y, q1.z};
                 thr = {q2.x, q2.y, q2.z};
@@ -533,17 +537,18 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
         }
         const bool shd_live = sh.on && survive, shd_dead = sh.on && !survive;
         if (survive) {
-            float4 *stp = a.st_out + (size_t)out_slot * WF_STATE_Q;
+            float4 *stp = a.st_out + out_slot;
+            const size_t cp = a.cap;
             const float4 q0 = {o.x, o.y, o.z, eta}, q1 = {d.x, d.y, d.z, prev_pdf}, q2 = {thr.x, thr.y, thr.z, __uint_as_float(home)},
                          q3 = {L.x, L.y, L.z, 0.0f};
             stp[0] = q0;
-            stp[1] = q1;
-            stp[2] = q2;
-            stp[3] = q3;
+            stp[cp] = q1;
+            stp[2u * cp] = q2;
+            stp[3u * cp] = q3;
             const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
             const float4 q4 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q5 = {sh.B.x, sh.B.y, sh.B.z, 0.0f};
-            stp[4] = shd_live ? q4 : z;
-            stp[5] = shd_live ? q5 : z;
+            stp[4u * cp] = shd_live ? q4 : z;
+            stp[5u * cp] = shd_live ? q5 : z;
         } else if (act) {  // the path ends (a pending shadow ray is added to this record by the next k_shade)
             const float4 rec = {L.x, L.y, L.z, 0.0f};
             Lh[home] = rec;
@@ -556,10 +561,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             n_shd_w += (uint32_t)__popcll(bl);
             if (shd_live) {
                 const uint32_t k = base + off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
-                float4 *rec = a.shd_out + (size_t)k * 4u;
+                float4 *rec = a.shd_out + k;
                 const float4 q0 = {sh.so.x, sh.so.y, sh.so.z, sh.tmax}, q1 = {sh.sdir.x, sh.sdir.y, sh.sdir.z, __uint_as_float(out_slot)};
                 rec[0] = q0;
-                rec[1] = q1;
+                rec[a.cap] = q1;
             }
         }
         const unsigned long long bd = __ballot(shd_dead);
@@ -571,14 +576,15 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             if (shd_dead) {
                 const uint32_t k =
                     base + WF_REGION - 1u - (off + __builtin_amdgcn_mbcnt_hi((uint32_t)(bd >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bd, 0u)));
-                float4 *rec = a.shd_out + (size_t)k * 4u;
+                float4 *rec = a.shd_out + k;
+                const size_t cp = a.cap;
                 const float4 q0 = {sh.so.x, sh.so.y, sh.so.z, sh.tmax},
                              q1 = {sh.sdir.x, sh.sdir.y, sh.sdir.z, __uint_as_float(WF_DEAD | k)},
                              q2 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q3 = {sh.B.x, sh.B.y, sh.B.z, __uint_as_float(home)};
                 rec[0] = q0;
-                rec[1] = q1;
-                rec[2] = q2;
-                rec[3] = q3;
+                rec[cp] = q1;
+                rec[2u * cp] = q2;
+                rec[3u * cp] = q3;
             }
         }
     }
@@ -598,18 +604,19 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
 }
 
 // upload of caller rays for Integrator.sample(): o, d [3][n] SoA + tmax -> path-state records (tmax rides in the eta slot)
-__global__ __launch_bounds__(256) void k_init_rays_wf(float4 *st, uint32_t *seg_cnt, uint32_t n_regions, uint32_t n, const float *o,
-                                                      const float *d, const float *tmax) {
+__global__ __launch_bounds__(256) void k_init_rays_wf(float4 *st, uint32_t cap, uint32_t *seg_cnt, uint32_t n_regions, uint32_t n,
+                                                      const float *o, const float *d, const float *tmax) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_regions) seg_cnt[i] = n > i * WF_REGION ? min(n - i * WF_REGION, WF_REGION) : 0u;
     if (i >= n) return;
-    float4 *s = st + (size_t)i * WF_STATE_Q;
+    float4 *s = st + i;
+    const size_t cp = cap;
     const float4 q0 = {o[i], o[n + i], o[2 * n + i], tmax[i]}, q1 = {d[i], d[n + i], d[2 * n + i], -1.0f},
                  q2 = {1.0f, 1.0f, 1.0f, __uint_as_float(i)}, q3 = {0.0f, 0.0f, 0.0f, 0.0f};
     s[0] = q0;
-    s[1] = q1;
-    s[2] = q2;
-    s[3] = q3;
-    s[4] = q3;
-    s[5] = q3;
+    s[cp] = q1;
+    s[2u * cp] = q2;
+    s[3u * cp] = q3;
+    s[4u * cp] = q3;
+    s[5u * cp] = q3;
 }

@@ -1101,7 +1101,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         HIPCHK(c, hipMemcpyAsync(io + 6 * (size_t)n, tmax, (size_t)n * 4, hipMemcpyHostToDevice, st));
         HIPCHK(c, hipMemsetAsync(rows, 0, (size_t)(2 + 2 * MAX_DEPTH_STATS) * n_rows * 8, st));
         HIPCHK(c, hipMemsetAsync(Lh, 0, (size_t)cap * 16, st));
-        hipLaunchKernelGGL(k_init_rays_wf, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, b.stA, b.segA, nseg, n, io,
+        hipLaunchKernelGGL(k_init_rays_wf, dim3(div_up(std::max(n, nseg), 256)), dim3(256), 0, st, b.stA, cap, b.segA, nseg, n, io,
                            io + 3 * (size_t)n, io + 6 * (size_t)n);
         WfArgs w{};
         w.sc = s->ds;

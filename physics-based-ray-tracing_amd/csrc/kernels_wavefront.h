@@ -303,15 +303,76 @@ struct WfShadow {
     float tmax;
     bool on;
 };
+// the 64-byte record of the primitive that was hit, in one batch of loads (so that the compiler cannot split it into
+// dependent pieces: type first, then the geometry of that type, then material / emitter)
+DEV pbrt_prim wf_load_prim(const pbrt_prim *p) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    struct Raw {
+        u32x4 q[4];
+    };
+    const u32x4 *q = reinterpret_cast<const u32x4 *>(p);
+    Raw r = {{q[0], q[1], q[2], q[3]}};
+    return __builtin_bit_cast(pbrt_prim, r);
+}
+struct WfVn {
+    float n[9];
+};
+DEV WfVn wf_load_vn(const float *vn, uint32_t slot) {  // vn != nullptr
+    typedef float __attribute__((ext_vector_type(3))) f3;
+    struct Raw {
+        f3 a, b, c;
+    };
+    const float *r = vn + 9u * slot;
+    WfVn o;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o.n[k] = r[k];
+    return o;
+}
+// make_si on the preloaded record (same statements as device_scene.h make_si / shading_normal)
+DEV SI wf_make_si(const pbrt_prim &P, V3 o, V3 d, float t, float u, float v, bool has_vn, const WfVn &vn) {
+    SI si;
+    if (P.type == PBRT_PRIM_SPHERE) {
+        V3 c = g3(P, 0);
+        V3 p = madd(d, t, o);
+        si.n = normalize(p - c);
+        si.p = madd(si.n, P.g[3], c);
+    } else if (P.type == PBRT_PRIM_CONE) {
+        const V3 r0 = g3(P, 0), r1 = g3(P, 4), r2 = g3(P, 8);
+        si.p = madd(d, t, o);
+        V3 no = {0.0f, 0.0f, -1.0f};
+        if (u == 0.0f) {
+            no = {dot(r0, si.p) + P.g[3], dot(r1, si.p) + P.g[7], 1.0f - (dot(r2, si.p) + P.g[11])};
+            if (!(dot(no, no) > 0.0f)) no = {0.0f, 0.0f, 1.0f};  // the apex itself
+        }
+        si.n = normalize(v3(fma_(r0.x, no.x, fma_(r1.x, no.y, r2.x * no.z)), fma_(r0.y, no.x, fma_(r1.y, no.y, r2.y * no.z)),
+                            fma_(r0.z, no.x, fma_(r1.z, no.y, r2.z * no.z))));
+    } else {
+        si.p = madd(g3(P, 6), v, madd(g3(P, 3), u, g3(P, 0)));
+        si.n = g3(P, 9);
+    }
+    si.ns = si.n;
+    if (has_vn && (P.type == PBRT_PRIM_TRIANGLE || P.type == PBRT_PRIM_PARALLELOGRAM)) {
+        const V3 n0 = {vn.n[0], vn.n[1], vn.n[2]}, n1 = {vn.n[3], vn.n[4], vn.n[5]}, n2 = {vn.n[6], vn.n[7], vn.n[8]};
+        if (dot(n0, n0) + dot(n1, n1) + dot(n2, n2) > 0.0f) {
+            if (P.type == PBRT_PRIM_PARALLELOGRAM) {
+                si.ns = normalize(n0);
+            } else {
+                const float b0 = 1.0f - u - v;
+                si.ns = normalize(madd(n0, b0, madd(n1, u, n2 * v)));
+            }
+        }
+    }
+    return si;
+}
+
 // bounce_step from the shading on, with the shadow ray handed out instead of traced (same statements, same order)
 template <int ACCEL>
-DEV bool wf_shade_step(const WfArgs &a, const Tables &tb, uint32_t depth, uint32_t ka, uint32_t kb, const Hit &h, V3 &o, V3 &d,
-                       V3 &thr, V3 &L, float &eta, float &prev_pdf, WfShadow &sh) {
+DEV bool wf_shade_step(const WfArgs &a, const Tables &tb, uint32_t depth, uint32_t ka, uint32_t kb, const Hit &h, const pbrt_prim &P,
+                       bool has_vn, const WfVn &vn, V3 &o, V3 &d, V3 &thr, V3 &L, float &eta, float &prev_pdf, WfShadow &sh) {
     bool survive = false;
     sh.on = false;
     const uint32_t nE = a.sc.n_emitters;
-    const pbrt_prim &P = tb.prims_by_slot[h.slot];
-    SI si = make_si<true>(P, o, d, h.t, h.u, h.v, a.sc.vnormals, h.slot);
+    SI si = wf_make_si(P, o, d, h.t, h.u, h.v, has_vn, vn);
     const int32_t emitter = P.emitter;
     const uint32_t mat_id = P.material;
     if (emitter >= 0) {
@@ -408,7 +469,9 @@ DEV Tables wf_tables_lds(const DevScene &sc, uint32_t *lds, uint32_t n_threads) 
 template <bool FIRST, bool TABS>
 __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_shade(const WfArgs a) {
     constexpr uint32_t T = WF_SHADE_THREADS, W = T / 64;
-    __shared__ uint32_t wlist[W][128];  // per wave: slots (within the region) of paths that hit something and wait for a full wave
+    // per wave: the paths that hit something and wait for a full wave -- slot within the region, and the hit record
+    __shared__ uint32_t wlist[W][128];
+    __shared__ float4 whit[W][128];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
     const uint32_t r = xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
@@ -449,33 +512,40 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
     uint32_t c0 = wid * 64u;         // the wave's next chunk of the region
     for (;;) {
         if (c0 < cnt_in) {
-            // ---- a chunk of hit records: paths whose ray left the scene end here, the others go on the list
+            // ---- a chunk of hit records: paths whose ray left the scene end here, the others go on the list.  One batch of
+            // loads: the hit record and (bounces >= 1) the four state planes a path that ends needs.
             const uint32_t s = c0 + lane;
-            bool is_hit = false;
-            if (s < cnt_in) {
-                const uint32_t id = __float_as_uint(a.hits[base + s].w);
-                is_hit = id != 0xffffffffu;
-                if (!is_hit) {
-                    if (FIRST) {
-                        const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-                        Lh[base + s] = z;
-                    } else {
-                        const float4 *stp = a.st_in + (base + s);
-                        const size_t cp = a.cap;
-                        const float4 q2 = stp[2u * cp], q4 = stp[4u * cp], q5 = stp[5u * cp];
-                        float4 Lv = stp[3u * cp];
-                        if (q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
-                            Lv.x = fma_(q4.x, q5.x, Lv.x);
-                            Lv.y = fma_(q4.y, q5.y, Lv.y);
-                            Lv.z = fma_(q4.z, q5.z, Lv.z);
-                        }
-                        Lv.w = 0.0f;
-                        Lh[__float_as_uint(q2.w)] = Lv;
-                    }
+            const bool valid = s < cnt_in;
+            float4 hr = {0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu)};
+            float4 q2 = {0, 0, 0, 0}, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = {0, 0, 0, 0};
+            if (valid) {
+                hr = a.hits[base + s];
+                if (!FIRST) {
+                    const float4 *stp = a.st_in + (base + s);
+                    const size_t cp = a.cap;
+                    q2 = stp[2u * cp];
+                    q3 = stp[3u * cp];
+                    q4 = stp[4u * cp];
+                    q5 = stp[5u * cp];
                 }
             }
+            const bool is_hit = __float_as_uint(hr.w) != 0xffffffffu;
+            if (valid && !is_hit) {
+                float4 Lv = q3;
+                if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
+                    Lv.x = fma_(q4.x, q5.x, Lv.x);
+                    Lv.y = fma_(q4.y, q5.y, Lv.y);
+                    Lv.z = fma_(q4.z, q5.z, Lv.z);
+                }
+                Lv.w = 0.0f;
+                Lh[FIRST ? base + s : __float_as_uint(q2.w)] = Lv;
+            }
             const unsigned long long bh = __ballot(is_hit);
-            if (is_hit) wlist[wid][list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u))] = s;
+            if (is_hit) {
+                const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
+                wlist[wid][e] = s;
+                whit[wid][e] = hr;
+            }
             __builtin_amdgcn_wave_barrier();  // other lanes of the wave read these entries below (LDS operations of a wave stay in order)
             list_n += (uint32_t)__popcll(bh);
             c0 += W * 64u;
@@ -495,13 +565,18 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
         uint32_t home = 0;
         if (act) {
             const uint32_t s = wlist[wid][list_n + lane];
-            const float4 hr = a.hits[base + s];
+            const float4 hr = whit[wid][list_n + lane];
             Hit h;
             h.t = hr.x;
             h.u = hr.y;
             h.v = hr.z;
             h.prim = __float_as_uint(hr.w);
             h.slot = h.prim;
+            // one batch of loads: the primitive's record, its vertex normals, the path state
+            const pbrt_prim P = wf_load_prim(tb.prims_by_slot + h.slot);
+            const bool has_vn = a.sc.vnormals != nullptr;  // uniform
+            WfVn vn;
+            if (has_vn) vn = wf_load_vn(a.sc.vnormals, h.slot);
             uint32_t ka, kb;
             if (FIRST) {
                 float tm;
@@ -523,7 +598,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);
             }
-            survive = wf_shade_step<ACCEL_K_BVH_GLOBAL>(a, tb, a.depth, ka, kb, h, o, d, thr, L, eta, prev_pdf, sh);
+            survive = wf_shade_step<ACCEL_K_BVH_GLOBAL>(a, tb, a.depth, ka, kb, h, P, has_vn, vn, o, d, thr, L, eta, prev_pdf, sh);
         }
         n_seg_w += take;
         // survivors -> front of the region of the `out` state
@@ -545,10 +620,10 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             stp[cp] = q1;
             stp[2u * cp] = q2;
             stp[3u * cp] = q3;
-            const float4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            const float4 q4 = {sh.A.x, sh.A.y, sh.A.z, 0.0f}, q5 = {sh.B.x, sh.B.y, sh.B.z, 0.0f};
-            stp[4u * cp] = shd_live ? q4 : z;
-            stp[5u * cp] = shd_live ? q5 : z;
+            const float4 q4 = {shd_live ? sh.A.x : 0.0f, shd_live ? sh.A.y : 0.0f, shd_live ? sh.A.z : 0.0f, 0.0f},
+                         q5 = {shd_live ? sh.B.x : 0.0f, shd_live ? sh.B.y : 0.0f, shd_live ? sh.B.z : 0.0f, 0.0f};
+            stp[4u * cp] = q4;
+            stp[5u * cp] = q5;
         } else if (act) {  // the path ends (a pending shadow ray is added to this record by the next k_shade)
             const float4 rec = {L.x, L.y, L.z, 0.0f};
             Lh[home] = rec;

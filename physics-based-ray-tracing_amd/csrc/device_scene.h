@@ -484,12 +484,15 @@ DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, c
     bvh_cex(key[0], key[2]);
     bvh_cex(key[1], key[3]);
     bvh_cex(key[1], key[2]);
+    // (the reference of the nearest child is picked before the branch: the four references then arrive with the rest of the
+    // node instead of in a second, dependent LDS read inside it)
+    const uint32_t s0 = key[0] & 3u;
+    const uint32_t near_ref = s0 == 0u ? w1.x : (s0 == 1u ? w1.y : (s0 == 2u ? w1.z : w1.w));
     if (key[0] == 0xffffffffu) {
         c.cur = bvh_pop(nodes, st, c, ovf);
         return;
     }
-    const uint32_t s0 = key[0] & 3u;
-    c.cur = s0 == 0u ? w1.x : (s0 == 1u ? w1.y : (s0 == 2u ? w1.z : w1.w));
+    c.cur = near_ref;
     const uint32_t n_more = (key[1] != 0xffffffffu ? 1u : 0u) + (key[2] != 0xffffffffu ? 1u : 0u) + (key[3] != 0xffffffffu ? 1u : 0u);
     // (slots of misses are 3, 3, ...: never looked at, the count says how many are real)
     const uint32_t entry = (node << 8) | (n_more << 6) | (key[1] & 3u) | ((key[2] & 3u) << 2) | ((key[3] & 3u) << 4);

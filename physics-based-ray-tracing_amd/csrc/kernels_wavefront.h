@@ -19,9 +19,9 @@
 // Layouts: float4 PLANES -- component q of record i at base[q * cap + i] -- so that the streaming accesses (a wave writes the
 // survivors it packed, reads the rays of consecutive queue entries, ends the missed paths of a chunk) are 1 KiB contiguous per
 // wave-instruction; only the state of the paths that hit something is gathered:
-//   path state, 96 B  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, home)  q3 = (L, -)
+//   path state, 96 B  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, -)  q3 = (L, home)
 //                     q4 = (A, visibility of the path's shadow ray: written 0 by k_shade, set by k_trace)  q5 = (B, -)
-//   hit, 16 B         (t, u, v, primitive index | 0xffffffff: none)
+//   hit               hit_id[i] = primitive index | 0xffffffff: none (4 B, all a path that ends needs);  hits[i] = (t, u, v, -)
 //   shadow ray, 64 B  q0 = (origin, tmax)  q1 = (direction, dest)  and, for paths that ended at the bounce that emitted it,
 //                     q2 = (A, visibility)  q3 = (B, home); dest = state slot of the survivor | WF_DEAD | own record index.
 //                     Rays of survivors fill a region's records from the front, rays of ended paths from the back.
@@ -53,7 +53,8 @@ struct WfArgs {
     DevScene sc;
     pbrt_camera cam;
     float4 *st_in, *st_out;      // [cap][6] path state
-    float4 *hits;                // [cap]
+    float4 *hits;                // [cap] (t, u, v, -) of the rays that hit something
+    uint32_t *hit_id;            // [cap] primitive index | 0xffffffff
     float4 *shd_in, *shd_out;    // [cap][4] shadow rays emitted by the previous / this bounce
     float *Lhome;                // [cap] float4 records (r, g, b, 0) indexed by home
     const uint32_t *seg_in, *nsh_in;   // per region: live paths; shadow rays of the previous bounce (survivors' | ended paths' << 16)
@@ -212,8 +213,11 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                 else
                     reinterpret_cast<float *>(a.st_in + 4u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // q4.w of the state
             } else {
-                const float4 rec = {best, hu, hv, __uint_as_float(found ? hid : 0xffffffffu)};
-                a.hits[rslot] = rec;
+                a.hit_id[rslot] = found ? hid : 0xffffffffu;
+                if (found) {
+                    const float4 rec = {best, hu, hv, 0.0f};
+                    a.hits[rslot] = rec;
+                }
             }
             busy = false;
         }
@@ -470,8 +474,7 @@ template <bool FIRST, bool TABS>
 __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_shade(const WfArgs a) {
     constexpr uint32_t T = WF_SHADE_THREADS, W = T / 64;
     // per wave: the paths that hit something and wait for a full wave -- slot within the region, and the hit record
-    __shared__ uint32_t wlist[W][128];
-    __shared__ float4 whit[W][128];
+    __shared__ uint32_t wlist[W][128], wprim[W][128];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
     const uint32_t r = xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
@@ -516,20 +519,19 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             // loads: the hit record and (bounces >= 1) the four state planes a path that ends needs.
             const uint32_t s = c0 + lane;
             const bool valid = s < cnt_in;
-            float4 hr = {0.0f, 0.0f, 0.0f, __uint_as_float(0xffffffffu)};
-            float4 q2 = {0, 0, 0, 0}, q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = {0, 0, 0, 0};
+            uint32_t hid = 0xffffffffu;
+            float4 q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = {0, 0, 0, 0};
             if (valid) {
-                hr = a.hits[base + s];
+                hid = a.hit_id[base + s];
                 if (!FIRST) {
                     const float4 *stp = a.st_in + (base + s);
                     const size_t cp = a.cap;
-                    q2 = stp[2u * cp];
                     q3 = stp[3u * cp];
                     q4 = stp[4u * cp];
                     q5 = stp[5u * cp];
                 }
             }
-            const bool is_hit = __float_as_uint(hr.w) != 0xffffffffu;
+            const bool is_hit = hid != 0xffffffffu;
             if (valid && !is_hit) {
                 float4 Lv = q3;
                 if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
@@ -538,13 +540,13 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                     Lv.z = fma_(q4.z, q5.z, Lv.z);
                 }
                 Lv.w = 0.0f;
-                Lh[FIRST ? base + s : __float_as_uint(q2.w)] = Lv;
+                Lh[FIRST ? base + s : __float_as_uint(q3.w)] = Lv;
             }
             const unsigned long long bh = __ballot(is_hit);
             if (is_hit) {
                 const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
                 wlist[wid][e] = s;
-                whit[wid][e] = hr;
+                wprim[wid][e] = hid;
             }
             __builtin_amdgcn_wave_barrier();  // other lanes of the wave read these entries below (LDS operations of a wave stay in order)
             list_n += (uint32_t)__popcll(bh);
@@ -565,14 +567,14 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
         uint32_t home = 0;
         if (act) {
             const uint32_t s = wlist[wid][list_n + lane];
-            const float4 hr = whit[wid][list_n + lane];
             Hit h;
+            h.prim = wprim[wid][list_n + lane];
+            h.slot = h.prim;
+            // one batch of loads: the hit, the primitive's record, its vertex normals, the path state
+            const float4 hr = a.hits[base + s];
             h.t = hr.x;
             h.u = hr.y;
             h.v = hr.z;
-            h.prim = __float_as_uint(hr.w);
-            h.slot = h.prim;
-            // one batch of loads: the primitive's record, its vertex normals, the path state
             const pbrt_prim P = wf_load_prim(tb.prims_by_slot + h.slot);
             const bool has_vn = a.sc.vnormals != nullptr;  // uniform
             WfVn vn;
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 if (q4.w != 0.0f) L = {fma_(q4.x, q5.x, L.x), fma_(q4.y, q5.y, L.y), fma_(q4.z, q5.z, L.z)};
                 eta = (a.key_mode == 1 && a.depth == 0) ? 1.0f : q0.w;  // caller rays carry tmax in the eta slot
                 prev_pdf = q1.w;
-                home = __float_as_uint(q2.w);
+                home = __float_as_uint(q3.w);
                 uint32_t px, py;
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);
@@ -614,8 +616,8 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
         if (survive) {
             float4 *stp = a.st_out + out_slot;
             const size_t cp = a.cap;
-            const float4 q0 = {o.x, o.y, o.z, eta}, q1 = {d.x, d.y, d.z, prev_pdf}, q2 = {thr.x, thr.y, thr.z, __uint_as_float(home)},
-                         q3 = {L.x, L.y, L.z, 0.0f};
+            const float4 q0 = {o.x, o.y, o.z, eta}, q1 = {d.x, d.y, d.z, prev_pdf}, q2 = {thr.x, thr.y, thr.z, 0.0f},
+                         q3 = {L.x, L.y, L.z, __uint_as_float(home)};
             stp[0] = q0;
             stp[cp] = q1;
             stp[2u * cp] = q2;
@@ -687,11 +689,11 @@ __global__ __launch_bounds__(256) void k_init_rays_wf(float4 *st, uint32_t cap, 
     float4 *s = st + i;
     const size_t cp = cap;
     const float4 q0 = {o[i], o[n + i], o[2 * n + i], tmax[i]}, q1 = {d[i], d[n + i], d[2 * n + i], -1.0f},
-                 q2 = {1.0f, 1.0f, 1.0f, __uint_as_float(i)}, q3 = {0.0f, 0.0f, 0.0f, 0.0f};
+                 q2 = {1.0f, 1.0f, 1.0f, 0.0f}, q3 = {0.0f, 0.0f, 0.0f, __uint_as_float(i)}, z = {0.0f, 0.0f, 0.0f, 0.0f};
     s[0] = q0;
     s[cp] = q1;
     s[2u * cp] = q2;
     s[3u * cp] = q3;
-    s[4u * cp] = q3;
-    s[5u * cp] = q3;
+    s[4u * cp] = z;
+    s[5u * cp] = z;
 }

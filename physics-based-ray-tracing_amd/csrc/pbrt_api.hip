@@ -534,7 +534,7 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
 
 // ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
 struct WfPlan {
-    uint32_t threads = 1024, rows = 2, grid_mult = 4;
+    uint32_t threads = 1024, rows = 2, grid_mult = 8;  // grid: ring 1024^2 x 64: 2 / 4 / 8 / 16 workgroups per CU -> 27.6 / 21.3 / 20.4 / 21.3 ms
     size_t lds = 0;
 };
 // Workgroup shape of k_trace: the image plus (rows + 1) stack rows per workgroup; two 1024-thread workgroups per CU when both fit
@@ -571,19 +571,20 @@ static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
 }
 struct WfBufs {
     float4 *stA, *stB, *hits, *shA, *shB;
-    uint32_t *segA, *segB, *nshA, *nshB;
+    uint32_t *hit_id, *segA, *segB, *nshA, *nshB;
 };
 static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
     b->stA = (float4 *)c->buf("wf_stateA", (size_t)cap * WF_STATE_Q * 16);
     b->stB = (float4 *)c->buf("wf_stateB", (size_t)cap * WF_STATE_Q * 16);
     b->hits = (float4 *)c->buf("wf_hits", (size_t)cap * 16);
+    b->hit_id = (uint32_t *)c->buf("wf_hit_id", (size_t)cap * 4);
     b->shA = (float4 *)c->buf("wf_shadowA", (size_t)cap * 64);
     b->shB = (float4 *)c->buf("wf_shadowB", (size_t)cap * 64);
     b->segA = (uint32_t *)c->buf("wf_segA", (size_t)nreg * 4);
     b->segB = (uint32_t *)c->buf("wf_segB", (size_t)nreg * 4);
     b->nshA = (uint32_t *)c->buf("wf_nshA", (size_t)nreg * 4);
     b->nshB = (uint32_t *)c->buf("wf_nshB", (size_t)nreg * 4);
-    return b->stA && b->stB && b->hits && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
+    return b->stA && b->stB && b->hits && b->hit_id && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
 }
 // The bounces of one pass.  camera: depth 0 generates its rays from the film keys (else the rays are in b.stA / b.segA).
 // Returns the number of launches through *launches.
@@ -606,6 +607,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         a.st_in = in;
         a.st_out = out;
         a.hits = b.hits;
+        a.hit_id = b.hit_id;
         a.shd_in = shi;
         a.shd_out = sho;
         a.seg_in = sin;
@@ -687,8 +689,8 @@ static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsi
     for (uint32_t d = 0; d < nd; ++d) {
         const uint64_t in = live[d], next = d + 1 < nd ? live[d + 1] : 0, h = hits[d];
         if (!in) break;
-        b += (d > 0 ? in * 32 : 0) + in * 16;                             // k_trace
-        b += in * 16 + (d > 0 ? (in - h) * 32 + h * 64 : 0);              // k_shade: hit records, state
+        b += (d > 0 ? in * 32 : 0) + in * 4 + h * 16;                     // k_trace: rays in, hit indices + hit records out
+        b += in * 4 + h * 16 + (d > 0 ? in * 48 + h * 96 : 0);            // k_shade: hit indices / records, state
         b += (in - next) * 16 + next * 64;                                // radiance records, survivors
     }
     return b + shadows * (36 + 64 + 96);

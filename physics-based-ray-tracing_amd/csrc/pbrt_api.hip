@@ -534,6 +534,7 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
 
 // ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
 struct WfPlan {
+    uint32_t grid_deep = 2;  // workgroups per CU from bounce 2 on (few rays: a resident round of larger shares; ring 8 / 2 / 1: 139.7 / 137.1 / 134.9 ms)
     uint32_t threads = 1024, rows = 2, grid_mult = 8;  // grid: ring 1024^2 x 64: 2 / 4 / 8 / 16 workgroups per CU -> 27.6 / 21.3 / 20.4 / 21.3 ms
     size_t lds = 0;
 };
@@ -556,6 +557,8 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     p.rows = std::max(2u, std::min(rows_fit, 8u));
     if (e_rows) p.rows = std::max(2u, std::min((uint32_t)atoi(e_rows), 15u));
     if (e_grid) p.grid_mult = std::max(1u, (uint32_t)atoi(e_grid));
+    static const char *e_deep = getenv("PBRT_WF_GRID_DEEP");
+    if (e_deep) p.grid_deep = std::max(1u, (uint32_t)atoi(e_deep));
     p.lds = (size_t)image + (size_t)p.rows * p.threads * 4u;
     return p;
 }
@@ -569,6 +572,7 @@ static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
     }
     return PBRT_OK;
 }
+#define WF_BYTES_PER_PATH (2 * WF_STATE_Q * 16 + 16 + 4 + 2 * 64 + 16)  // two state sets, hit, hit index, two shadow sets, Lhome
 struct WfBufs {
     float4 *stA, *stB, *hits, *shA, *shB;
     uint32_t *hit_id, *segA, *segB, *nshA, *nshB;
@@ -592,7 +596,8 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     pbrt_ctx *c = s->ctx;
     hipStream_t st = c->stream;
     const bool lds = s->accel_kernel == ACCEL_K_BVH_LDS;
-    const uint32_t G = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_mult * (uint32_t)c->n_cu));
+    const uint32_t G0 = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_mult * (uint32_t)c->n_cu));
+    const uint32_t G2 = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_deep * (uint32_t)c->n_cu));
     a.n_regions = nreg;
     a.lds_bytes = lds ? s->lds_bytes : 0u;
     a.stk_rows = p.rows;
@@ -614,6 +619,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         a.seg_out = sout;
         a.nsh_in = have_shadows ? ni : nullptr;
         a.nsh_out = no;
+        const uint32_t G = depth >= 2 ? G2 : G0;
         if (first) {
             if (lds)
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
@@ -719,14 +725,29 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const bool brute_scene = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
     // round 2, chains of up to six bounces per launch (one launch per pass on the Cornell box): 2 / 4 / 8 / 16 / 32 / 64 Mi -> 7.85 / 7.01 /
     // 6.72 / 6.56 / 6.49 / 6.43 ms
+    // round 3, BVH scenes as trace / shade streams (twelve launches per pass: their tails and the thinly filled late bounces weigh
+    // less in larger passes): ring 1024^2 x 64: 1 / 2 / 4 / 8 / 16 / 32 / 64 Mi -> 50.8 / 37.6 / 25.5 / 22.2 / 19.6 / 18.0 / 17.3 ms;
+    // 64 Mi paths = 23 GB of workspace (356 B per path in flight); the fused BVH kernels (PBRT_FILM_NO_HIT_POOL) keep 16 Mi
+    const bool wf_scene = !brute_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
+    // and beyond: 1024^2 x 512: 64 / 128 / 256 Mi -> 144 / 134 / 115 ms.  Default: the largest power of two whose workspace
+    // (WF_BYTES_PER_PATH per path in flight) fits 40 % of the free device memory, 16 .. 256 Mi (95 GB of the 288 GB of an MI355X)
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (64u << 20) : (16u << 20));
+    if (!f->pass_paths && wf_scene) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+        for (const DevBuf *b : {&c->ws["wf_stateA"], &c->ws["wf_stateB"], &c->ws["wf_shadowA"], &c->ws["wf_shadowB"], &c->ws["wf_hits"],
+                                &c->ws["wf_hit_id"], &c->ws["Lhome"]})
+            free_b += b->bytes;  // what this context already holds is re-used, not allocated on top
+        pass_paths = 16u << 20;
+        while (pass_paths < (256u << 20) && 2 * pass_paths * WF_BYTES_PER_PATH <= (uint64_t)(0.4 * (double)free_b)) pass_paths *= 2;
+    }
     uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
     s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
     NEED(c, npix_r * s_pass < 0xfffffc00ull);
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
     const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
-    NEED(c, (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the state arrays are addressed through 32-bit buffer offsets
+    NEED(c, wf_scene || (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the tiled state arrays are addressed through 32-bit buffer offsets
     // BVH scenes: intersection and shading as separate streams (kernels_wavefront.h); PBRT_FILM_NO_HIT_POOL keeps the fused
     // k_bounce (one launch per bounce, shading in the lanes the traversal leaves) as the A/B reference
     const bool bvh_scene = s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS;

@@ -24,29 +24,30 @@ static bool tri_hit(const float *g, V3 o, V3 d, float tmax, float *t) {
     return true;
 }
 static const uint32_t SENT = 0xffffffffu;
+// device_scene.h BvhStack / bvh_push / bvh_pop: one entry per node (index << 8 | count << 6 | sorted slots), the newest in `tos`
 struct Stack {
-    uint32_t rows[64]; uint32_t n_rows; uint32_t ovf[40];
+    uint32_t rows[64]; uint32_t n_rows; uint32_t ovf[30];
     uint32_t cur, tos, sp;
 };
-static void push3(Stack &c, uint32_t n, uint32_t e1, uint32_t e2, uint32_t e3) {
-    for (uint32_t k = 0; k < 3; ++k) {
-        uint32_t e = k == 0 ? c.tos : (k == 1 ? (n == 3 ? e3 : e2) : e2), row = c.sp + k;
-        if (k < n) { if (row < c.n_rows) c.rows[row] = e; else c.ovf[std::min(row - c.n_rows, 39u)] = e; }
+static void push(Stack &c, bool on, uint32_t entry) {
+    if (!on) return;
+    if (c.sp < c.n_rows) c.rows[c.sp] = c.tos; else c.ovf[std::min(c.sp - c.n_rows, 29u)] = c.tos;
+    c.sp += 1; c.tos = entry;
+}
+static uint32_t pop(const HostBvh4 &b4, Stack &c) {
+    const uint32_t e = c.tos;
+    if (e == SENT) return SENT;
+    const uint32_t ref = b4.nodes[e >> 8].child[e & 3u], n = (e >> 6) & 3u;
+    if (n > 1u) {
+        c.tos = (e & 0xffffff00u) | ((n - 1u) << 6) | ((e & 0x3fu) >> 2);
+    } else {
+        const uint32_t sp1 = c.sp - 1u;
+        c.tos = sp1 < c.n_rows ? c.rows[sp1] : c.ovf[std::min(sp1 - c.n_rows, 29u)];
+        c.sp = sp1;
     }
-    c.sp += n;
-    c.tos = n ? e1 : c.tos;
+    return ref;
 }
-static uint32_t pop(Stack &c) {
-    uint32_t r = c.tos, sp1 = c.sp > 0 ? c.sp - 1 : 0;
-    uint32_t nxt = c.rows[std::min(sp1, c.n_rows - 1)];
-    if (sp1 >= c.n_rows) nxt = c.ovf[std::min(sp1 - c.n_rows, 39u)];
-    c.tos = nxt; c.sp = sp1;
-    return r;
-}
-static void cex(uint32_t &ka, uint32_t &ra, uint32_t &kb, uint32_t &rb) {
-    bool sw = ka > kb; uint32_t lo = std::min(ka, kb), hi = std::max(ka, kb), r0 = sw ? rb : ra, r1 = sw ? ra : rb;
-    ka = lo; kb = hi; ra = r0; rb = r1;
-}
+static void cex(uint32_t &ka, uint32_t &kb) { uint32_t lo = std::min(ka, kb), hi = std::max(ka, kb); ka = lo; kb = hi; }
 int main(int argc, char **argv) {
     std::vector<pbrt_prim> prims;
     float v[9];
@@ -96,32 +97,33 @@ int main(int argc, char **argv) {
     for (auto &P : prims) for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], P.g[c]); hi[c] = std::max(hi[c], P.g[c]); }
     const uint32_t n_rows = argc > 1 ? (uint32_t)atoi(argv[1]) : 4;
     uint64_t mism = 0, visits = 0, maxsp = 0, runaway = 0;
-    const int NR = 200000;
+    const int NR = argc > 2 ? atoi(argv[2]) : 200000;
     for (int r = 0; r < NR; ++r) {
         V3 o{lo[0] + (hi[0] - lo[0]) * (0.5f + U(rng)), lo[1] + (hi[1] - lo[1]) * (0.5f + U(rng)), lo[2] + (hi[2] - lo[2]) * (0.5f + U(rng))};
         V3 d{U(rng), U(rng), U(rng)};
         float l = std::sqrt(dot(d, d)); if (!(l > 1e-3f)) continue;
         d = {d.x / l, d.y / l, d.z / l};
-        if (r % 7 == 0) d.x = 0; if (r % 11 == 0) d.y = 0;
+        if (r % 7 == 0) d.x = 0;
+        if (r % 11 == 0) d.y = 0;
         float bt = INFINITY; uint32_t bi = SENT;
         for (uint32_t i = 0; i < n; ++i) { float t; if (tri_hit(prims[i].g, o, d, bt, &t) && (bi == SENT || t < bt || (t == bt && i < bi))) { bt = t; bi = i; } }
         const float tiny = 1e-18f;
         V3 ds{std::fabs(d.x) < tiny ? std::copysign(tiny, d.x) : d.x, std::fabs(d.y) < tiny ? std::copysign(tiny, d.y) : d.y, std::fabs(d.z) < tiny ? std::copysign(tiny, d.z) : d.z};
-        V3 inv{1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z}, oi{o.x * inv.x, o.y * inv.y, o.z * inv.z};
+        V3 inv{1.0f / ds.x, 1.0f / ds.y, 1.0f / ds.z};
         Stack c{}; c.n_rows = n_rows; c.cur = 0; c.tos = SENT; c.sp = 0;
         float best = INFINITY; uint32_t hid = SENT; bool found = false; uint64_t vis = 0;
         for (;;) {
             while ((int32_t)c.cur >= 0) {
                 if (++vis > 100000) break;
                 const HostNode4 &N = b4.nodes[c.cur];
-                float A[3], B[3]; const float iv[3] = {inv.x, inv.y, inv.z}, oo[3] = {oi.x, oi.y, oi.z};
+                float A[3], B[3]; const float iv[3] = {inv.x, inv.y, inv.z}, oc[3] = {o.x, o.y, o.z};
                 uint32_t qn[3], qf[3];
                 for (int a = 0; a < 3; ++a) {
                     uint32_t eb = ((N.exps >> (8 * a)) & 0xff) << 23; float s; memcpy(&s, &eb, 4);
-                    A[a] = s * iv[a]; B[a] = fmaf(N.org[a], iv[a], -oo[a]);
+                    A[a] = s * iv[a]; B[a] = (N.org[a] - oc[a]) * iv[a];
                     bool neg = iv[a] < 0; qn[a] = neg ? N.qhi[a] : N.qlo[a]; qf[a] = neg ? N.qlo[a] : N.qhi[a];
                 }
-                uint32_t key[4], ref[4] = {N.child[0], N.child[1], N.child[2], N.child[3]};
+                uint32_t key[4];
                 for (int k = 0; k < 4; ++k) {
                     float tn = 0, tf = best;
                     for (int a = 0; a < 3; ++a) {
@@ -131,12 +133,13 @@ int main(int argc, char **argv) {
                     uint32_t tb; memcpy(&tb, &tn, 4);
                     key[k] = (tn <= tf) ? ((tb & ~3u) | (uint32_t)k) : SENT;
                 }
-                cex(key[0], ref[0], key[1], ref[1]); cex(key[2], ref[2], key[3], ref[3]); cex(key[0], ref[0], key[2], ref[2]);
-                cex(key[1], ref[1], key[3], ref[3]); cex(key[1], ref[1], key[2], ref[2]);
-                uint32_t nm = (key[1] != SENT) + (key[2] != SENT) + (key[3] != SENT);
-                push3(c, nm, ref[1], ref[2], ref[3]);
+                cex(key[0], key[1]); cex(key[2], key[3]); cex(key[0], key[2]); cex(key[1], key[3]); cex(key[1], key[2]);
+                if (key[0] == SENT) { c.cur = pop(b4, c); continue; }
+                const uint32_t node = c.cur;
+                c.cur = N.child[key[0] & 3u];
+                const uint32_t nm = (key[1] != SENT) + (key[2] != SENT) + (key[3] != SENT);
+                push(c, nm != 0, (node << 8) | (nm << 6) | (key[1] & 3u) | ((key[2] & 3u) << 2) | ((key[3] & 3u) << 4));
                 maxsp = std::max<uint64_t>(maxsp, c.sp);
-                c.cur = key[0] == SENT ? pop(c) : ref[0];
             }
             if (vis > 100000) { ++runaway; break; }
             if (c.cur == SENT) break;
@@ -145,7 +148,7 @@ int main(int argc, char **argv) {
                 float t; uint32_t id = lp[first + k].meta & 0x0fffffffu;
                 if (tri_hit(lp[first + k].g, o, d, best, &t) && (!found || t < best || (t == best && id < hid))) { best = t; hid = id; found = true; }
             }
-            c.cur = pop(c);
+            c.cur = pop(b4, c);
         }
         visits += vis;
         if ((found ? hid : SENT) != bi || (found && best != bt)) ++mism;

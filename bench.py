@@ -17,12 +17,20 @@ N > 1            BASELINE config 5: the same scene at 4096 x 4096, 1024 spp (17.
                  reduce(sum)) | testring (config 4: TestRing/TestRing.obj, 1024 x 1024, 512 spp, LDS-resident BVH;
                  N > 1: bands + gather).  Default: cbox at N = 1, cbox4k at N > 1.
 
+With no --config at N = 1 the line also carries `also`: the other named scenes of BASELINE.json (us_sphere_box = config 3,
+testring = config 4, cbox4k = config 5 on one GPU), 3 steps each after the headline steps, each with its own roofline and its L2
+against the CPU port on a bounded sample; and `seeds`: the headline render at seeds 1 and 2.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernel (k_bounce / k_us_bounce): ALGORITHMIC HBM bytes of its launches (DESIGN.md byte
-                  model, evaluated on the live-path counters of this very run) / their HIP-event durations on the
-                  library's stream, against 8 TB/s.  `traffic` (HBM bytes per launch from rocprofv3 PMC passes) is NOT
-                  measured by this run: it is copied from profiles/pmc_traffic.json only if that file was recorded for
-                  the kernel sources this run uses (sha256 of csrc/), else null -- `traffic_source` says which.
+  roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace + k_shade).  These kernels run against VALU ISSUE, not
+                  HBM, so bound = "valu": frac = valu_issue_busy x lane_active (the share of the chip's
+                  f32 lane-slots that did useful work), achieved = frac x peak (78.6 T lane-ops/s = 256 CUs x 4 SIMD-32 x
+                  2.4 GHz).  Both factors come from SQ counters of rocprofv3 PMC passes and are copied from
+                  profiles/pmc_traffic.json only if that file was recorded for the kernel sources this run uses (sha256 of
+                  csrc/), else frac / achieved are null.  The HBM side rides along as hbm_* keys: hbm_achieved = ALGORITHMIC
+                  bytes of the launches (DESIGN.md byte model, evaluated on the live-path counters of this very run) / their
+                  HIP-event durations on the library's stream, against 8 TB/s; `traffic` = HBM bytes per launch from the PMC
+                  passes (same file, same hash guard), `traffic_source` says which.
   cpu_baseline -- the CPU oracle (C++ port of the same algorithm, same RNG: the reference's Python / Mitsuba path
                   cannot run on this box) on the host cores, on a bounded sample of the same workload (~15 s), rank 0,
                   N = 1 only; the same run gives the per-pixel L2 between the HIP result and the CPU result.
@@ -45,6 +53,7 @@ if ROOT not in sys.path:
 PKG = "physics-based-ray-tracing_amd"
 SCENES = os.path.join(ROOT, "tests", "scenes")
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T f32 lane-operations per second
 
 CONFIGS = {
     "cbox": dict(kind="radiance", scene="cbox.xml", res=512, spp=256, max_depth=6, band_rows=0, baseline_config=2,
@@ -81,6 +90,11 @@ def kernel_source_hash():
 
 def launch_ranks(args, argv):
     """--gpus N > 1 outside torchrun: start the ranks as fresh children of a parent that has not initialised the GPU."""
+    # under rocprofv3 the profiler's preloaded library has initialised the GPU in THIS process already and the children would
+    # inherit the preload: refuse (profile multi-rank runs rank by rank, `rocprofv3 ... -- python3 bench.py` under torchrun's env)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ):
+        print("bench.py: --gpus N > 1 would launch ranks from a profiled process; run one rank per rocprofv3 instead", file=sys.stderr)
+        return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -99,10 +113,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=-1, help="-1: 2 for cbox / us_sphere_box, 1 for the larger workloads")
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="N = 1 default run: only the headline, not the other named scenes / seeds")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU work of the cpu_baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0: min(visible cores, 64)")
     ap.add_argument("--res", type=int, default=0, help="override the film size (rehearsals only: not the named workload)")
     ap.add_argument("--spp", type=int, default=0, help="override spp / paths per ray (rehearsals only)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="under torchrun with ONE rank: initialise the nccl (RCCL) process group anyway and issue the gather / reduce at "
+                         "world size 1 -- runs torch's bundled RCCL beside libpbrt_hip.so in one process on a 1-GPU box")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses device 0 and the collective runs over gloo "
                          "(host staging); exercises sharding + stitching, NOT RCCL -- numbers are not benchmark numbers")
@@ -138,7 +156,8 @@ def main():
         sys.exit("bench.py needs an MI355X: the ray-transport hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force = bool(args.force_collective and "WORLD_SIZE" in os.environ)
+    if world > 1 or force:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -147,7 +166,35 @@ def main():
 
     mi = importlib.import_module(PKG)
     par = importlib.import_module(PKG + ".parallel")
-    seed = 0
+    env = dict(mi=mi, par=par, np=np, torch=torch, dist=dist, device=device, rank=rank, world=world, args=args, force=force)
+    out = measure(env, name, cfg, steps, warmup, seed=0, overridden=overridden, with_cpu=(world == 1 and not args.no_cpu_baseline))
+    if rank == 0 and world == 1 and args.config is None and not overridden and not args.no_also:
+        # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line
+        out["also"] = []
+        for other in ("us_sphere_box", "testring", "cbox4k"):
+            o = measure(env, other, dict(CONFIGS[other]), 3, 1, seed=0, overridden=False, with_cpu=not args.no_cpu_baseline,
+                        cpu_seconds=min(args.cpu_seconds, 6.0))
+            keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline", "l2_vs_cpu_ref", "cpu_baseline", "config")
+                    if k in o}
+            out["also"].append(keep)
+        out["seeds"] = {"0": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
+        for sd in (1, 2):  # seeds 0, 1, 2
+            o = measure(env, name, dict(cfg), 5, 1, seed=sd, overridden=False, with_cpu=False)
+            out["seeds"][str(sd)] = {"value": o["value"], "ms_per_step": o["ms_per_step"]}
+        if not args.no_cpu_baseline:
+            out["seeds"]["parity"] = seed_parity(env, cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 or force:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_seconds=None):
+    """W untimed + K timed steps of one named workload; rank 0 gets the result record (others None)."""
+    mi, par, np, torch, dist = env["mi"], env["par"], env["np"], env["torch"], env["dist"]
+    device, rank, world, args = env["device"], env["rank"], env["world"], env["args"]
     radiance = cfg["kind"] == "radiance"
     if radiance:
         RES, SPP = cfg["res"], cfg["spp"]
@@ -176,7 +223,7 @@ def main():
         acc["samples"] += st["samples"]
 
     def barrier():
-        if world > 1:
+        if world > 1 or env["force"]:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,9 +236,9 @@ def main():
             keep["tile"] = tile
             if args.rehearse_on_one_gpu and world > 1:
                 tile = tile.cpu()  # gloo gathers host tensors
-            return par.gather_film(tile, layout, RES, RES, rank, world)
+            return par.gather_film(tile, layout, RES, RES, rank, world, force_collective=env["force"])
         buf = par.distributed_acquire(scene, PPR, seed=seed, device=device, on_call=account,
-                                      host_collective=bool(args.rehearse_on_one_gpu and world > 1))
+                                      host_collective=bool(args.rehearse_on_one_gpu and world > 1), force_collective=env["force"])
         return buf
 
     for _ in range(warmup):
@@ -215,7 +262,7 @@ def main():
         value = total_units / (dt / steps) / 1e6
         achieved = (acc["bounce_bytes"] / 1e9) / (acc["bounce_ms"] / 1e3) if acc["bounce_ms"] > 0 else 0.0
         traffic, traffic_source = None, "not measured by this run (HBM bytes need separate rocprofv3 --pmc passes)"
-        valu_busy = None
+        valu_busy = lane_active = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         src_hash = kernel_source_hash()
         if os.path.exists(pmc):
@@ -224,6 +271,7 @@ def main():
                 if rec and rec.get("kernel_source_sha16") == src_hash:
                     traffic = rec.get("hbm_bytes_per_launch")
                     valu_busy = rec.get("valu_issue_busy")
+                    lane_active = rec.get("lane_active")
                     traffic_source = f"profiles/pmc_traffic.json[{name}] recorded on these kernel sources ({src_hash}): {rec.get('how', '')}"
                 elif rec:
                     traffic_source += f"; profiles/pmc_traffic.json[{name}] is for sources {rec.get('kernel_source_sha16')}, this run uses {src_hash}"
@@ -238,44 +286,64 @@ def main():
             workload = f"{cfg['scene']} ({cfg['what']}), {PPR} paths per ray; {sharding}"
         if overridden:
             workload += "  [SIZE OVERRIDDEN ON THE COMMAND LINE: not the named BASELINE workload]"
+        kernel = "k_us_bounce" if not radiance else ("k_trace + k_shade" if name == "testring" else "k_bounce")
+        frac = round(valu_busy * lane_active, 4) if (valu_busy is not None and lane_active is not None) else None
         out = {
             "metric": cfg["metric"], "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if (world == 1 and name == "cbox") else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": cfg["baseline_config"], "samples_per_step": total_units, "seed": seed,
                        "mean_segments_per_sample": round(acc["segments"] / max(acc["samples"], 1), 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_bounce" if radiance else "k_us_bounce", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "traffic_source": traffic_source,
+            # the roof these kernels run against is VALU issue, dead lanes taken out
+            "roofline": {"bound": "valu", "kernel": kernel,
+                         "achieved": round(frac * VALU_PEAK_TLANEOPS, 2) if frac is not None else None,
+                         "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T f32 lane-op/s", "frac": frac,
+                         "valu_issue_busy": valu_busy, "lane_active": lane_active,
+                         "valu_source": ("SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) and SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the "
+                                         "dominant kernels, 4th pass of tools/profile_bench.sh (a wave64 VALU instruction occupies its SIMD-32 "
+                                         "for 2 cycles; 1024 SIMDs, the counters are summed over 32 shader engines)"
+                                         if valu_busy is not None else "not recorded for these kernel sources"),
+                         "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
+                         "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(acc["bounce_bytes"] / max(acc["launches"], 1)),
                          "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 5), "launches": acc["launches"],
                          "kernel_ms_per_step": round(acc["kernel_ms"] / steps, 3), "scope": "rank 0's launches of the timed steps"},
         }
-        # the ceiling these kernels actually run against (not one of the contract's two bounds, so it rides along as extra keys):
-        # VALU instruction issue, from the SQ counters of the same profile passes as `traffic`
-        out["roofline"]["valu_issue_busy"] = valu_busy
-        out["roofline"]["valu_issue_busy_source"] = (
-            "SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) of the dominant kernels, 4th pass of tools/profile_bench.sh (a wave64 VALU instruction "
-            "occupies its SIMD-32 for 2 cycles; 1024 SIMDs, the counter is summed over 32 shader engines)"
-            if valu_busy is not None else "not recorded for these kernel sources")
         if radiance and name in ("cbox", "cbox4k"):
             out["roofline"]["note"] = ("the brute-force bounce kernels walk up to six bounces of a path in registers (the library picks the chain "
                                        "lengths from the path survival of the scene's last render; Cornell box: one launch per pass), so the "
-                                       "only HBM traffic left is one 16-byte radiance record per path: the HBM fraction is reported because the "
-                                       "contract asks for it, the kernels are VALU-issue bound (valu_issue_busy; DESIGN.md section 7)")
+                                       "only HBM traffic left is one 16-byte radiance record per path (hbm_* keys)")
+        if radiance and name == "testring":
+            out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
+                                       "8 waves per SIMD) and k_shade (full waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")
         if not radiance:
-            out["roofline"]["note"] = ("k_us_bounce is VALU-issue bound (GGX / impedance sample, expf, sinf, acosf; one launch walks "
-                                       "every bounce of a pass), not HBM bound: the HBM fraction is reported because the contract asks for it; "
-                                       "see profiles/ for SQ_INSTS_VALU")
+            out["roofline"]["note"] = ("k_us_bounce (GGX / impedance sample, expf, sinf, acosf; one launch walks every bounce of a pass)")
         if args.rehearse_on_one_gpu and world > 1:
             out["rehearsal"] = rehearsal_check(mi, np, scene, cfg, result, seed, world)
-        if world == 1 and not args.no_cpu_baseline:
-            out.update(cpu_baseline(mi, np, scene, cfg, name, seed, args))
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if env["force"]:
+            out["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                 "what": "gather / reduce issued through torch.distributed at world size 1 (RCCL in this process)"}
+        if with_cpu:
+            out.update(cpu_baseline(mi, np, scene, cfg, name, seed, args, cpu_seconds))
     return out
+
+
+def seed_parity(env, cfg):
+    """seeds 1 and 2 of the headline scene against the CPU port at 16 spp (bit for bit, like seed 0)"""
+    mi, np = env["mi"], env["np"]
+    from oracle import binding as ob
+    scene = mi.load_file(os.path.join(SCENES, cfg["scene"]), res=cfg["res"], spp=16, max_depth=cfg["max_depth"])
+    integ, sens = scene.integrator(), scene.sensors()[0]
+    osc = ob.OracleScene.from_scene(scene)
+    cores = env["args"].cpu_threads or min(len(os.sched_getaffinity(0)), 64)
+    rec = {}
+    for sd in (1, 2):
+        ref = osc.render(sens.camera(), integ._film_desc(scene, sens, sd, 16), n_threads=cores)
+        img = integ.render(scene, seed=sd, spp=16)
+        d = img.astype(np.float64) - ref.astype(np.float64)
+        rec[str(sd)] = {"rmse": float(np.sqrt(np.mean(d * d))), "bit_exact_fraction": float(np.mean(img == ref)),
+                        "compared_on": f"{cfg['res']}x{cfg['res']} x 16 spp"}
+    return rec
 
 
 def rehearsal_check(mi, np, scene, cfg, result, seed, world):
@@ -293,10 +361,11 @@ def rehearsal_check(mi, np, scene, cfg, result, seed, world):
             "rel_l2_vs_unsharded": float(np.linalg.norm(got - whole) / (np.linalg.norm(whole) + 1e-30))}
 
 
-def cpu_baseline(mi, np, scene, cfg, name, seed, args):
+def cpu_baseline(mi, np, scene, cfg, name, seed, args, cpu_seconds=None):
     """The CPU oracle on a bounded sample of the same workload, and the L2 between the two results on that sample."""
     from oracle import binding as ob
     cores = args.cpu_threads or min(len(os.sched_getaffinity(0)), 64)
+    budget = cpu_seconds if cpu_seconds is not None else args.cpu_seconds
     osc = ob.OracleScene.from_scene(scene)
     if cfg["kind"] == "radiance":
         integ, sens = scene.integrator(), scene.sensors()[0]
@@ -308,7 +377,7 @@ def cpu_baseline(mi, np, scene, cfg, name, seed, args):
         osc.render(sens.camera(), integ._film_desc(scene, sens, seed, 2, crop=crop), n_threads=cores)
         per_spp = (time.perf_counter() - tc) / 2
         spp = 1
-        while spp < SPP and per_spp * spp * 2 <= args.cpu_seconds:
+        while spp < SPP and per_spp * spp * 2 <= budget:
             spp *= 2
         fd = integ._film_desc(scene, sens, seed, spp, crop=crop)
         tc = time.perf_counter()
@@ -317,8 +386,14 @@ def cpu_baseline(mi, np, scene, cfg, name, seed, args):
         img = integ.render(scene, seed=seed, spp=spp, crop=crop)
         d = img.astype(np.float64) - ref.astype(np.float64)
         where = f"{RES}x{RES}" if crop is None else f"the centred {crop[2]}x{crop[3]} crop of the {RES}x{RES} film"
+        # single-thread figure: the same film at 1 spp on one thread
+        ts = time.perf_counter()
+        osc.render(sens.camera(), integ._film_desc(scene, sens, seed, 1, crop=crop), n_threads=1)
+        t1 = time.perf_counter() - ts
         return {"cpu_baseline": {"value": round(px * spp / tcpu / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-                                 "sample": f"{cfg['scene']} {where} x {spp} spp (of {SPP}), {tcpu:.1f} s, C++ oracle, std::thread over rows"},
+                                 "sample": f"{cfg['scene']} {where} x {spp} spp (of {SPP}), {tcpu:.1f} s, C++ oracle, std::thread over rows",
+                                 "single_thread": {"value": round(px / t1 / 1e6, 4), "unit": "Msamples/s", "cores": 1,
+                                                   "sample": f"{where} x 1 spp, {t1:.1f} s"}},
                 "l2_vs_cpu_ref": {"rmse": float(np.sqrt(np.mean(d * d))), "max_abs": float(np.abs(d).max()),
                                   "bit_exact_fraction": float(np.mean(img == ref)), "tolerance": 1e-3,
                                   "compared_on": f"{where} x {spp} spp, seed {seed}"}}
@@ -328,7 +403,7 @@ def cpu_baseline(mi, np, scene, cfg, name, seed, args):
     osc.us_acquire(ui.us_params(scene), seed, 64)
     per_path = (time.perf_counter() - tc) / 64
     ppr = 64
-    while ppr < cfg["ppr"] and per_path * ppr * 2 <= args.cpu_seconds:
+    while ppr < cfg["ppr"] and per_path * ppr * 2 <= budget:
         ppr *= 2
     tc = time.perf_counter()
     ref, _ = osc.us_acquire(ui.us_params(scene), seed, ppr)

@@ -75,12 +75,14 @@ def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=N
     return tile, layout
 
 
-def gather_film(tile, layout, width, height, rank, world_size, group=None):
-    """One gather of every rank's tile to rank 0, then de-interleave.  -> [H, W, 3] tensor on rank 0, None elsewhere."""
+def gather_film(tile, layout, width, height, rank, world_size, group=None, force_collective=False):
+    """One gather of every rank's tile to rank 0, then de-interleave.  -> [H, W, 3] tensor on rank 0, None elsewhere.
+    force_collective: issue the gather even at world_size 1 (a process group must be initialised): runs the collective
+    library on a box with one GPU."""
     import torch
 
     dist = _dist()
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         parts = [tile]
     else:
         parts = [torch.empty_like(tile) for _ in range(world_size)] if rank == 0 else None
@@ -110,7 +112,7 @@ def distributed_render(scene, spp, seed=0, band_rows=64, render_band=None, devic
 
 
 def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None, apply_pulse=None,
-                        on_call=None, host_collective=False):
+                        on_call=None, host_collective=False, force_collective=False):
     """Ultrasound: every rank traces its path range into its own (already normalised) channel buffer;
     one reduce(sum) to rank 0.  acquire(offset, count, norm, out_tensor) fills the tensor; the default
     calls the HIP library on the tensor's device memory.  With pulse_model 'gaussian' rank 0 convolves the reduced
@@ -137,14 +139,17 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
                         out_dev=buf.data_ptr(), pulse=False)
             if on_call is not None:
                 on_call()
-    if world > 1:
+    if world > 1 or (force_collective and dist.is_initialized()):
         if host_collective:  # gloo rehearsal on one GPU: the collective runs on host tensors
             buf = buf.cpu()
         dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
     if rank != 0:
         return None
     if apply_pulse is None:
-        apply_pulse = getattr(ui, "pulse_model", "impulse") == "gaussian"
+        # what the kernel was actually told: echoes deposited without the carrier (PBRT_USQ_NO_CARRIER) still want their pulse.
+        # (pulse_model sets that bit; a caller who edits `quirks` afterwards must not get a doubly / never convolved buffer.)
+        from . import _capi
+        apply_pulse = bool(int(ui.us_params(scene).quirks) & _capi.USQ_NO_CARRIER)
     if apply_pulse:
         # pulse_model 'gaussian': the shards hold bare echo amplitudes; the pulse is linear, so ONE convolution of the
         # reduced buffer equals the single-GPU result (UltraIntegrator._acquire applies it to its host buffer).

@@ -128,3 +128,23 @@ def test_bench_rehearsal_of_the_ultrasound_split(tmp_path):
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["config"]["baseline_config"] == 3 and "one reduce(sum)" in out["config"]["workload"]
     assert out["rehearsal"]["rel_l2_vs_unsharded"] <= 1e-5 and out["config"]["samples_per_step"] == 5 * 64 * 4096
+
+
+def test_rccl_path_runs_beside_the_library_at_world_size_one(tmp_path):
+    """The collective of the multi-GPU job, executed on the one GPU a test box has: bench.py under torch.distributed.run with ONE
+    rank and --force-collective initialises the nccl (= RCCL) process group, renders config 5's bands into a torch tensor and issues
+    the gather at world size 1, then the ultrasound reduce -- torch's bundled librccl / libamdhip64 and libpbrt_hip.so in one process
+    (the runtime-mapping order of _capi.load_library).  A fresh child process; nothing re-executes a process that touched the GPU."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for cfg, extra in (("cbox4k", ["--spp", "4"]), ("us_sphere_box", ["--spp", "64"])):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+               "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--config", cfg, "--force-collective", "--steps", "1",
+               "--warmup", "0", "--no-cpu-baseline"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["collective"]["backend"] == "nccl" and out["collective"]["world_size"] == 1
+        assert out["n_gpus"] == 1 and out["value"] > 0

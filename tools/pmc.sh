@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/raw -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline "$@" > $OUT/run.log 2>&1 || { tail -20 $OUT/run.log; exit 1; }
+rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT/raw -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also "$@" > $OUT/run.log 2>&1 || { tail -20 $OUT/run.log; exit 1; }
 python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict

@@ -21,13 +21,17 @@ b = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(b):
     shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
 kernel = "k_us_bounce" if config.startswith("us_") else "k_bounce"
+# BVH scenes: a bounce is k_trace + k_shade (kernels_wavefront.h)
+families = (kernel, kernel + "_pool") if config != "testring" else ("k_trace", "k_shade")
+if config == "testring":
+    kernel = "k_trace + k_shade"
 
 
 def per_dispatch(sub, ctr):
     f = max(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)  # newest run
     tot, n = {}, {}
     rows = [r for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == ctr and any(k + "<" in r["Kernel_Name"] for k in (kernel, kernel + "_pool"))]
+            if r["Counter_Name"] == ctr and any(k + "<" in r["Kernel_Name"] for k in families)]
     # the first render of a brute-force scene starts with a 2-spp probe pass (the library learns its launch plan from it): those
     # small launches are not the workload -- keep the dispatches of the full-size grid only
     gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
@@ -49,17 +53,22 @@ if "k_bounce_hbm_bytes_per_launch" in allrec:   # round-1 layout: keep it under 
     allrec = {"r01_cbox": allrec}
 # VALU-issue utilisation of the dominant kernel family (4th pass of profile_bench.sh): a wave64 VALU instruction occupies its SIMD-32
 # for 2 cycles, SQ_BUSY_CYCLES is summed over the 32 shader engines of the 1024 SIMDs -> busy = SQ_INSTS_VALU / (16 * SQ_BUSY_CYCLES)
-valu_busy = None
+valu_busy = lane_active = None
 try:
     iv, ni = per_dispatch("pmc_sq", "SQ_INSTS_VALU")
     bc, nb = per_dispatch("pmc_sq", "SQ_BUSY_CYCLES")
     tot_c = sum(bc[k] * nb[k] for k in bc)
     valu_busy = round(sum(iv[k] * ni[k] for k in iv) / (16.0 * tot_c), 4) if tot_c else None
+    # share of the lanes active per VALU instruction (idle lanes of a chain launch, partial waves, divergence)
+    tc, nt = per_dispatch("pmc_sq", "SQ_THREAD_CYCLES_VALU")
+    ai, na = per_dispatch("pmc_sq", "SQ_ACTIVE_INST_VALU")
+    tot_a = sum(ai[k] * na[k] for k in ai)
+    lane_active = round(sum(tc[k] * nt[k] for k in tc) / (64.0 * tot_a), 4) if tot_a else None
 except (ValueError, KeyError):
     pass
 allrec[config] = {
     "kernel": kernel, "hbm_bytes_per_launch": round(num / max(sum(nf.values()), 1)), "kernel_source_sha16": kernel_source_hash(),
-    "valu_issue_busy": valu_busy,
+    "valu_issue_busy": valu_busy, "lane_active": lane_active,
     "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --config {config} --steps 2 "
            f"--warmup 0 --no-cpu-baseline` (tools/profile_bench.sh {tag}); bytes = ({fetch_factor:g}*FETCH_SIZE + {write_factor:g}*WRITE_SIZE)*1024 "
            f"per dispatch, averaged over the {kernel} dispatches; FETCH factor: tools/pmc_calibrate.sh on the kernel's own "

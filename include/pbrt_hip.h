@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PBRT_ABI_VERSION 2
+#define PBRT_ABI_VERSION 3
 
 /* ---- error classes ------------------------------------------------------------------------ */
 #define PBRT_OK 0
@@ -268,7 +268,19 @@ typedef struct pbrt_stats {
     uint64_t model_bytes;  /* algorithmic HBM bytes of the last call (DESIGN.md byte model) */
     uint64_t bounce_model_bytes;
     uint64_t live[16];     /* paths entering depth d (d = 0..15), summed over passes          */
+    /* how the last call was launched (ABI 3).  The launch plan of a brute-force scene is state of the pbrt_scene: unless the
+     * caller sets one (PBRT_FILM_FUSE_PLAN) it is learnt from the path survival of the scene's previous render, so TIMINGS depend
+     * on the call history of a scene -- films never do. */
+    uint32_t fuse_plan;    /* bit d: the launch that walks bounce d goes on with bounce d + 1 (brute-force scenes; 0 for BVH scenes) */
+    uint32_t plan_source;  /* PBRT_PLAN_* */
+    uint64_t pass_paths;   /* paths in flight per pass */
+    uint64_t workspace_bytes; /* device memory the context holds after the call */
 } pbrt_stats;
+#define PBRT_PLAN_CALLER 0u  /* pbrt_film_desc.flags carried PBRT_FILM_FUSE_PLAN */
+#define PBRT_PLAN_LEARNT 1u  /* from the path survival of the scene's previous render */
+#define PBRT_PLAN_PROBED 2u  /* first render of the scene: from a 2-spp probe pass at the start of this call */
+#define PBRT_PLAN_DEFAULT 3u /* first render, too few samples for a probe: the library default (pairs) */
+#define PBRT_PLAN_STREAMS 4u /* BVH scenes: one k_trace + one k_shade launch per bounce */
 
 typedef struct pbrt_ctx pbrt_ctx;
 typedef struct pbrt_scene pbrt_scene;

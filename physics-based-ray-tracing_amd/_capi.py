@@ -6,6 +6,7 @@ The structures below mirror include/pbrt_hip.h field for field.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbrt_hip.so")  # override: A/B builds
 
-PBRT_ABI_VERSION = 2
+PBRT_ABI_VERSION = 3
 
 # primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
@@ -135,7 +136,8 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("kernel_ms", C.c_double), ("bounce_ms", C.c_double), ("bounce_launches", C.c_uint32),
                 ("passes", C.c_uint32), ("model_bytes", C.c_uint64), ("bounce_model_bytes", C.c_uint64),
-                ("live", C.c_uint64 * 16)]
+                ("live", C.c_uint64 * 16), ("fuse_plan", C.c_uint32), ("plan_source", C.c_uint32),
+                ("pass_paths", C.c_uint64), ("workspace_bytes", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}
@@ -229,6 +231,24 @@ def load_library(path: str | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+@contextlib.contextmanager
+def use_library(path: str):
+    """Inside the block the package talks to ANOTHER build of the library (its own contexts; scenes loaded inside are bound to it):
+    the diagnostic build libpbrt_hip_diag.so (make -C csrc diag: A/B launch structures the product library leaves out)."""
+    global _lib, _default_ctx
+    saved = (_lib, _default_ctx)
+    _lib = load_library(path)
+    _default_ctx = {}
+    try:
+        yield
+    finally:
+        _lib, _default_ctx = saved
+
+
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libpbrt_hip_diag.so")
+PLAN_CALLER, PLAN_LEARNT, PLAN_PROBED, PLAN_DEFAULT, PLAN_STREAMS = 0, 1, 2, 3, 4
 
 
 def addr(a: np.ndarray | None):

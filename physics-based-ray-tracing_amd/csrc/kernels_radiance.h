@@ -116,7 +116,8 @@ struct RadArgs {
     uint32_t *seg_out;
     unsigned long long *stats;  // [k][stat_stride] per-segment rows: k = 0 segments, 1 shadow rays, 2 + d live paths entering depth d
     uint32_t stat_stride;
-    uint32_t cap;
+    uint32_t cap;        // slots of Lhome
+    uint32_t state_cap;  // slots of the `in` / `out` state (<= cap: a pass whose bounces all run in one launch needs none)
     uint32_t n_paths;  // paths generated by the first bounce of this pass
     uint32_t depth, max_depth, rr_depth, seed;
     uint32_t nb;  // bounces this launch walks (the multi-bounce variants k_bounce<.., 2>; 2 .. MAX_CHAIN)
@@ -405,6 +406,10 @@ template <bool FIRST, int ACCEL, int NB = 1>
 #endif
 __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUTE ? FUSED_WAVES_PER_EU : BIG_WAVES_PER_EU) : seg_waves_per_eu(ACCEL)) void k_bounce(const RadArgs a) {
     static_assert(NB == 1 || ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "fused bounces: brute-force kernels only");
+    // the per-bounce survivor counts of a chain are packed 10 bits each per WORKGROUP and summed by thread 0: one segment per region,
+    // workgroup-level compaction (a -DREGION_SEGS_BRUTE / -DPBRT_BRUTE_DYN build would silently lose them)
+    static_assert(NB == 1 || (rad_region_segs(ACCEL) == 1 && !rad_wave_private(ACCEL) && seg_threads(ACCEL) <= 1023),
+                  "chain launches: REGION == SEG, workgroup scan");
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];  // double-buffered across the chunk loop: one barrier per chunk
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     if (ACCEL == ACCEL_K_BRUTE && (FIRST || PERWAVE)) fill_tables_lds(a.sc, tab_lds, SEG);  // (PERWAVE: no barrier in the walk)
 
     const uint32_t cap = a.cap;
-    const Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
+    const Rsrc r_in = make_rsrc(a.in, a.state_cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, a.state_cap * (N_STATE * 4u));
     const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
     uint32_t out_off = 0;      // survivors written so far (front of this region of the `out` state)
     uint32_t ns_acc = 0, nh_acc = 0, live_acc = 0, mid_acc = 0, mid_acc_hi = 0;
@@ -677,6 +682,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     }
 }
 
+#ifdef PBRT_DIAG  // launch structures that lost their A/B: kept for the diagnostic build only (make diag)
 // ---- k_walk: ONE launch walks every remaining bounce (brute-force kernels) -----------------------------------------------
 // Compaction is local to the segment, so nothing forces a grid-wide barrier between bounces: the workgroup that owns a
 // segment carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers (release
@@ -725,7 +731,7 @@ __global__ __launch_bounds__(SEG_BRUTE, WALK_WAVES_PER_EU) void k_walk(const Rad
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     if (ACCEL == ACCEL_K_BRUTE && FIRST) fill_tables_lds(a.sc, tab_lds, live_threads);
     const uint32_t cap = a.cap;
-    Rsrc r_in = make_rsrc(a.in, cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (N_STATE * 4u));
+    Rsrc r_in = make_rsrc(a.in, a.state_cap * (N_STATE * 4u)), r_out = make_rsrc(a.out, a.state_cap * (N_STATE * 4u));
     const Rsrc r_L = make_rsrc(a.Lhome, cap * 16u);
     uint32_t depth = a.depth, trip = 0, left = 0;
     uint32_t ns_acc = 0, nh_acc = 0;
@@ -939,6 +945,8 @@ __global__ __launch_bounds__(REGEN_WG, REGEN_WAVES_PER_EU) void k_regen(const Ra
         row[(2 + lane) * stride] += n;
     }
 }
+
+#endif  // PBRT_DIAG
 
 // column sums of the per-segment statistics: out[k] += sum_seg stats[k][seg].  grid (rows, REDUCE_SLICES): every block sums
 // one slice of a row and adds it to the row's total with one 64-bit atomic (out is zeroed by the caller; a single block
@@ -1173,6 +1181,7 @@ __global__ __launch_bounds__(256) void k_init_rays(float *st, uint32_t *seg_cnt,
     s[14 * 64] = __uint_as_float(i);
 }
 
+#ifdef PBRT_DIAG  // the fused BVH bounce kernels (k_bounce<.., BVH>) and their repack pass: diagnostic build only
 // ---- repack (BVH kernels, depth >= 2): deal the live paths evenly to as few workgroups as fill the GPU ----------
 // Per-wave compaction keeps every path inside the 512 slots its wave owns.  When few paths are left (open scenes:
 // 22 % after two bounces of the ring scene, 1 % after five) every workgroup still stages the whole scene in LDS for
@@ -1229,3 +1238,4 @@ __global__ __launch_bounds__(256) void k_repack_copy(const float *__restrict__ i
         for (int k = 0; k < N_STATE; ++k) d[k * 64] = v[k];
     }
 }
+#endif  // PBRT_DIAG

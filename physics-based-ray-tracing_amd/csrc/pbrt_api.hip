@@ -428,6 +428,7 @@ int pbrt_scene_destroy(pbrt_scene *s) {
 #define PBRT_DEFAULT_WALK_FROM 0xffu
 #endif
 
+#ifdef PBRT_DIAG
 template <bool FIRST>
 static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb0) {
     hipStream_t st = s->ctx->stream;
@@ -443,6 +444,7 @@ static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t
             hipLaunchKernelGGL((k_walk<FIRST, ACCEL_K_BRUTE_BIG, 1>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
     }
 }
+#endif
 // nb: bounces this launch walks (>= 2: the multi-bounce variants of the brute-force kernels, kernels_radiance.h; a.nb = nb)
 template <bool FIRST>
 static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
@@ -460,12 +462,17 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32
             else
                 hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
+#ifdef PBRT_DIAG  // the fused BVH bounce (PBRT_FILM_NO_HIT_POOL): diagnostic build only
         case ACCEL_K_BVH_GLOBAL:
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
             break;
         default:
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
             break;
+#else
+        default:
+            break;
+#endif
     }
 }
 
@@ -473,10 +480,12 @@ static int set_lds_attr(pbrt_scene *s) {
     if (s->accel_kernel != ACCEL_K_BVH_LDS) return PBRT_OK;
     pbrt_ctx *c = s->ctx;
     int bytes = (int)s->lds_bytes;
+#ifdef PBRT_DIAG
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<true, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+#endif
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<true, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<false, ACCEL_K_BVH_LDS>),
@@ -711,6 +720,14 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     NEED(c, f->spp > 0 && f->max_depth > 0 && f->filter <= PBRT_FILTER_GAUSSIAN);
     NEED(c, (uint64_t)W * H <= 0xffffffffull);
     HIPCHK(c, hipSetDevice(c->device));
+#ifndef PBRT_DIAG
+    {   // launch structures that lost their A/B live in the diagnostic build only (make -C csrc diag -> libpbrt_hip_diag.so)
+        const bool bvh = s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS;
+        if ((f->flags & (PBRT_FILM_REGEN | PBRT_FILM_WALK_SET)) || (bvh && (f->flags & PBRT_FILM_NO_HIT_POOL)))
+            return c->fail(PBRT_E_UNSUPPORTED, "PBRT_FILM_REGEN / PBRT_FILM_WALK_FROM / PBRT_FILM_NO_HIT_POOL select diagnostic launch "
+                                               "structures: build libpbrt_hip_diag.so (make -C csrc diag)");
+    }
+#endif
     int rc = set_lds_attr(s);
     if (rc) return rc;
     const uint32_t R = f->filter == PBRT_FILTER_BOX ? 0 : (f->filter == PBRT_FILTER_TENT ? 1 : 2);
@@ -761,8 +778,11 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         wfp = wf_plan(s);
         if ((rc = wf_set_attr(s, wfp)) != 0) return rc;
     }
-    float *stA = wavefront ? (float *)wfb.stA : (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
-    float *stB = wavefront ? (float *)wfb.stB : (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    // Brute-force scenes: the ping-pong path state (2 x 60 B per slot, 8 GB at 64 Mi paths) is only touched by a pass that needs
+    // more than one bounce launch; with the plan that walks every bounce in one launch (the Cornell box) it is never written, so it
+    // is allocated per pass, for the paths of THAT pass, when its plan says so (state_for below).
+    float *stA = wavefront ? (float *)wfb.stA : nullptr;
+    float *stB = wavefront ? (float *)wfb.stB : nullptr;
     float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
     // fused BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
     const bool repack = bvh_scene && !wavefront && rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
@@ -782,7 +802,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     const size_t segstats_bytes = (size_t)stat_rows * n_rows * 8;  // reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", (size_t)(2 + 2 * MAX_DEPTH_STATS) * n_rows * 8);
     if (!segstats) return PBRT_E_NOMEM;
-    if (!stA || !stB || !Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
+    if (!Lhome || !segA || !segB || !acc || !dstats) return PBRT_E_NOMEM;
     // k_bounce_pool launches also count the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
     const bool hit_pool = wavefront;  // k_shade counts the rays of every depth that hit something (rows HIT_ROW0 + d, for the byte model)
     const uint32_t hit_rows = hit_pool ? stat_rows - 2 : 0;
@@ -798,6 +818,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     uint32_t passes = 0, launches = 0;
     // the fuse plan of this call: the caller's, or the one learnt from the last render of this scene, or the library default
     const bool brute_scene_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
+    const bool plan_was_learnt = brute_scene_k && s->plan_hint_valid;
     uint32_t call_plan = !brute_scene_k ? 0u
                          : (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? ((f->flags >> 8) & 0xffu)
                          : (s->plan_hint_valid ? s->plan_hint : PBRT_DEFAULT_FUSE_PLAN);
@@ -821,6 +842,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.stats = segstats;
         a.stat_stride = n_rows;
         a.cap = cap;
+        a.state_cap = cap;
         a.n_paths = (uint32_t)(npix_r * sc);
         a.max_depth = f->max_depth;
         a.rr_depth = f->rr_depth;
@@ -841,6 +863,15 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         a.film_h = H;
         a.lds_bytes = s->lds_bytes;
         const uint32_t nseg_pass = div_up(a.n_paths, REGION);
+        if (!wavefront) {  // state for this pass: none if one launch walks all its bounces
+            const bool one_launch = brute_scene_k && !(f->flags & (PBRT_FILM_WALK_SET | PBRT_FILM_REGEN)) &&
+                                    chain_len(call_plan, 0, f->max_depth) >= f->max_depth;
+            const size_t need = one_launch ? (size_t)REGION : (size_t)nseg_pass * REGION;
+            stA = (float *)c->buf("stateA", need * N_STATE * 4);
+            stB = (float *)c->buf("stateB", need * N_STATE * 4);
+            if (!stA || !stB) return PBRT_E_NOMEM;
+            a.state_cap = (uint32_t)need;
+        }
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
         const bool brute = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
@@ -875,7 +906,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             n_ev += 2;
             HIPCHK(c, hipEventRecord(e0, st));
             if ((rc = wf_bounces(s, w, wfb, wfp, nseg_pass, true, &launches)) != 0) return rc;
-        } else if (brute && (f->flags & PBRT_FILM_REGEN)) {
+        }
+#ifdef PBRT_DIAG
+        else if (brute && (f->flags & PBRT_FILM_REGEN)) {
             // persistent waves with path regeneration (k_regen): one launch per pass, as many workgroups as the GPU holds at once
             int per_cu = 0;
             const void *fn = s->accel_kernel == ACCEL_K_BRUTE ? reinterpret_cast<const void *>(&k_regen<ACCEL_K_BRUTE>)
@@ -897,7 +930,9 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 hipLaunchKernelGGL(k_regen<ACCEL_K_BRUTE_BIG>, dim3(grid), dim3(REGEN_WG), 0, st, a);
             HIPCHK(c, hipGetLastError());
             ++launches;
-        } else
+        }
+#endif
+        else
         for (uint32_t depth = 0; depth < f->max_depth;) {
             // bounces this launch walks: 2 at the depths of the fuse plan (brute-force kernels; the last bounce of a
             // path only looks for emitters, so it is never worth a launch slot of its own either)
@@ -908,6 +943,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             a.out = out;
             a.seg_in = sin;
             a.seg_out = sout;
+#ifdef PBRT_DIAG
             if (repack && depth >= 2) {
                 // Only the regions THIS pass launched take part: a short last pass (spp not a multiple of the pass size)
                 // launches nseg_pass < nseg workgroups, so paths dealt to regions >= nseg_pass would never be traced, and
@@ -920,6 +956,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 a.in = stC;
                 a.seg_in = segC;
             }
+#endif
             // ONE event pair per pass around its bounce launches (a pair per launch costs ~8 us of queue bubbles each)
             if (depth == 0) {
                 pass_e1 = c->event(n_ev + 1);
@@ -929,12 +966,15 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                 HIPCHK(c, hipEventRecord(e0, st));
             }
             const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
+#ifdef PBRT_DIAG
             if (walk) {
                 if (depth == 0)
                     launch_walk<true>(s, a, nseg_pass, nb);
                 else
                     launch_walk<false>(s, a, nseg_pass, nb);
-            } else if (depth == 0) {
+            } else
+#endif
+            if (depth == 0) {
                 launch_bounce<true>(s, a, nseg_pass, nb);
             } else {
                 launch_bounce<false>(s, a, nseg_pass, nb);
@@ -1038,6 +1078,14 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     S.bounce_ms = bounce_ms;
     S.bounce_launches = launches;
     S.passes = passes;
+    S.fuse_plan = call_plan;
+    S.plan_source = wavefront ? PBRT_PLAN_STREAMS
+                    : (f->flags & PBRT_FILM_FUSE_PLAN_SET) ? PBRT_PLAN_CALLER
+                    : probe ? PBRT_PLAN_PROBED
+                    : plan_was_learnt ? PBRT_PLAN_LEARNT : PBRT_PLAN_DEFAULT;
+    S.pass_paths = (uint64_t)npix_r * s_pass;
+    S.workspace_bytes = 0;
+    for (const auto &kv : c->ws) S.workspace_bytes += kv.second.bytes;
     uint64_t tot, bb;
     for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     const bool brute_k = s->accel_kernel == ACCEL_K_BRUTE || s->accel_kernel == ACCEL_K_BRUTE_BIG;
@@ -1180,6 +1228,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     a.stats = segstats;
     a.stat_stride = n_rows;
     a.cap = cap;
+    a.state_cap = cap;
     a.n_paths = n;
     a.max_depth = max_depth;
     a.rr_depth = rr_depth;

@@ -267,50 +267,98 @@ def test_full_size_energy_sanity(cbox_full):
     assert img[:, 342:].mean(axis=(0, 1)).argmax() == 0   # right third by the red wall
 
 
-def test_bvh_scene_at_scale_queue_and_repack(mi, ob, capi):
-    """the ring scene with a few hundred regions: chunk queue, per-region slot reservation and the re-dealing of the
-    live paths before bounces >= 2 (k_scan_owners / k_repack_copy) change slot order only -- same film with and
-    without the repack, with other pass sizes, and equal to the oracle on a band"""
+def diag_renders(mi, capi, scene, load_kw, renders, accel=None):
+    """the same scene through the DIAGNOSTIC build of the library (libpbrt_hip_diag.so: the launch structures the product build
+    leaves out): -> [(film, stats)] for every kwargs dict in `renders`"""
+    out = []
+    with capi.use_library(capi.DIAG_LIB_PATH):
+        sc = mi.load_file(scene_path(scene), **load_kw)
+        if accel is not None:
+            sc.accel = accel
+        integ = sc.integrator()
+        for kw in renders:
+            img = integ.render(sc, **kw)
+            out.append((img, mi.default_context().stats()))
+        sc._dev = None  # the handle belongs to the diagnostic library's context
+    return out
+
+
+def test_bvh_scene_at_scale_streams_and_the_fused_kernels(mi, ob, capi):
+    """the ring scene with a few hundred regions.  Product path: a bounce is k_trace (stream of ray queries, several regions per
+    workgroup) + k_shade (per-wave lists, slot reservation): same film with other pass sizes, with the tree in global memory, and
+    equal to the oracle on a band.  Diagnostic build: the fused bounce kernels (PBRT_FILM_NO_HIT_POOL), with and without the
+    re-dealing of the live paths before bounces >= 2 -- same film, same segments, shadow rays and per-depth path counts."""
     sc = mi.load_file(scene_path("testring.xml"), res=320, spp=12)
     integ = sc.integrator()
     img = integ.render(sc, seed=2, spp=12)
-    assert np.array_equal(img, integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_REPACK))
-    assert np.array_equal(img, integ.render(sc, seed=2, spp=12, pass_paths=300_000))      # 5 passes of 2-3 samples
+    st = mi.default_context().stats()
+    assert st["plan_source"] == capi.PLAN_STREAMS and st["fuse_plan"] == 0 and st["workspace_bytes"] > 0
+    assert np.array_equal(img, integ.render(sc, seed=2, spp=12, pass_paths=300_000))      # 6 passes of 2 samples
+    assert mi.default_context().stats()["passes"] == 6
     assert np.array_equal(img, integ.render(sc, seed=2, spp=12))                           # slot order is not deterministic
     band = (0, 150, 320, 24)
     ref, _ = oracle_render(ob, sc, 2, 12, crop=band)
     assert np.array_equal(img[150:174], ref) and img.mean() > 0
-    st = mi.default_context().stats()
     assert st["samples"] == 320 * 320 * 12 and st["live"][0] == st["samples"] and st["live"][2] < st["live"][1] < st["live"][0]
-    # bounces >= 1 run in k_bounce_pool (a stream of closest-hit queries, shading in full waves) unless switched off: same
-    # film, same segments, shadow rays and per-depth path counts either way, with the LDS image and with the tree in global memory
-    img0 = integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL)
-    st0 = mi.default_context().stats()
-    assert np.array_equal(img0, img)
-    assert list(st0["live"]) == list(st["live"]) and st0["segments"] == st["segments"] and st0["shadow_rays"] == st["shadow_rays"]
-    assert np.array_equal(integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL | capi.FILM_NO_REPACK), img)
     scg = mi.load_file(scene_path("testring.xml"), res=320, spp=12)
     scg.accel = capi.ACCEL_BVH_GLOBAL
-    ig = scg.integrator()
-    assert np.array_equal(ig.render(scg, seed=2, spp=12), img)
-    assert np.array_equal(ig.render(scg, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL), img)
+    assert np.array_equal(scg.integrator().render(scg, seed=2, spp=12), img)
+    with pytest.raises(RuntimeError, match="diagnostic"):   # the product build does not carry the fused BVH kernels
+        integ.render(sc, seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL)
+    for accel in (None, capi.ACCEL_BVH_GLOBAL):
+        rs = diag_renders(mi, capi, "testring.xml", dict(res=320, spp=12),
+                          [dict(seed=2, spp=12), dict(seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL),
+                           dict(seed=2, spp=12, flags=capi.FILM_NO_HIT_POOL | capi.FILM_NO_REPACK)], accel=accel)
+        for im, s0 in rs:
+            assert np.array_equal(im, img)
+            assert list(s0["live"]) == list(st["live"]) and s0["segments"] == st["segments"] and s0["shadow_rays"] == st["shadow_rays"]
 
 
-def test_bvh_repack_with_a_short_last_pass(mi, ob, capi):
+def test_bvh_with_a_short_last_pass(mi, ob, capi):
     """spp that does not split into equal passes: 13 samples at 300 000 paths per pass are 6 passes of 2 and one of 1,
-    so the last pass launches half the regions the workspace was sized for.  The re-dealing of the live paths before
-    bounces >= 2 must stay inside the regions that pass launched (and must not read the counters the previous pass
-    left behind in the others); an odd max_depth leaves survivors in both counter arrays."""
+    so the last pass launches half the regions the workspace was sized for (the queue of a k_trace workgroup must stay inside the
+    regions that pass launched; an odd max_depth leaves survivors in both counter arrays).  Diagnostic build: the fused kernels'
+    re-dealing of the live paths under the same conditions."""
     sc = mi.load_file(scene_path("testring.xml"), res=320, spp=13, max_depth=7)
     integ = sc.integrator()
     img = integ.render(sc, seed=3, spp=13)
     short = integ.render(sc, seed=3, spp=13, pass_paths=300_000)
     assert np.array_equal(short, img)
-    assert np.array_equal(integ.render(sc, seed=3, spp=13, pass_paths=300_000, flags=capi.FILM_NO_REPACK), img)
     assert mi.default_context().stats()["passes"] == 7
     band = (0, 160, 320, 16)
     ref, _ = oracle_render(ob, sc, 3, 13, crop=band)
     assert np.array_equal(short[160:176], ref)
+    rs = diag_renders(mi, capi, "testring.xml", dict(res=320, spp=13, max_depth=7),
+                      [dict(seed=3, spp=13, pass_paths=300_000, flags=capi.FILM_NO_HIT_POOL),
+                       dict(seed=3, spp=13, pass_paths=300_000, flags=capi.FILM_NO_HIT_POOL | capi.FILM_NO_REPACK)])
+    assert all(np.array_equal(im, img) for im, _ in rs)
+
+
+def test_first_render_of_a_scene_probes_its_launch_plan(mi, capi):
+    """the launch plan of a brute-force scene is state of the scene: the FIRST render (plan left to the library, >= 16 spp) spends
+    a 2-spp probe pass on learning it, later renders use what the previous one measured.  Either way the film, the per-depth path
+    counts, the segments and the shadow rays are those of one launch per bounce; pbrt_stats says which plan ran and why."""
+    for scene, kw in (("cbox.xml", dict(res=40)), ("cone_room.xml", dict(res=32))):   # both brute-force kernel variants
+        for spp in (16, 37):
+            ref_sc = mi.load_file(scene_path(scene), spp=spp, **kw)
+            base = ref_sc.integrator().render(ref_sc, seed=9, spp=spp, flags=capi.film_fuse_plan(0))
+            st0 = mi.default_context().stats()
+            assert st0["plan_source"] == capi.PLAN_CALLER and st0["fuse_plan"] == 0
+            sc = mi.load_file(scene_path(scene), spp=spp, **kw)   # a freshly loaded scene: no plan yet
+            integ = sc.integrator()
+            first = integ.render(sc, seed=9, spp=spp)
+            st1 = mi.default_context().stats()
+            second = integ.render(sc, seed=9, spp=spp)
+            st2 = mi.default_context().stats()
+            assert np.array_equal(first, base) and np.array_equal(second, base)
+            for st in (st1, st2):
+                assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+            assert st1["plan_source"] == capi.PLAN_PROBED and st2["plan_source"] == capi.PLAN_LEARNT
+            assert st1["passes"] == st2["passes"] + 1 and st1["fuse_plan"] == st2["fuse_plan"] != 0
+        few = mi.load_file(scene_path(scene), spp=6, **kw)   # too few samples for a probe: the default plan (pairs)
+        few.integrator().render(few, seed=9, spp=6)
+        st = mi.default_context().stats()
+        assert st["plan_source"] == capi.PLAN_DEFAULT and st["fuse_plan"] == 0x15
 
 
 @pytest.mark.parametrize("scene,kw", [("cbox.xml", dict(res=48, max_depth=6)), ("cbox.xml", dict(res=32, max_depth=5)),
@@ -339,19 +387,20 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
     # the library's own choice: pairs for the first render of a scene, then the plan learnt from its path survival
     assert np.array_equal(integ.render(sc, seed=5, spp=6), base) and np.array_equal(integ.render(sc, seed=5, spp=6), base)
     assert list(ctx.stats()["live"]) == list(st0["live"])
-    # k_walk: one launch walks every remaining bounce of a pass (PBRT_FILM_WALK_FROM), with and without a fused first trip
-    for plan, walk in ((0x0, 0), (0x1, 0), (0x0, 1), (0x1, 2), (0x4, 2), (0x0, 3)):
-        img = integ.render(sc, seed=5, spp=6, flags=capi.film_fuse_plan(plan) | capi.film_walk_from(walk))
-        st = ctx.stats()
-        assert np.array_equal(img, base), (hex(plan), walk)
-        assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+    # the launch structures that lost their A/B live in the diagnostic build only
+    with pytest.raises(RuntimeError, match="diagnostic"):
+        integ.render(sc, seed=5, spp=6, flags=capi.FILM_REGEN)
+    # k_walk: one launch walks every remaining bounce of a pass (PBRT_FILM_WALK_FROM), with and without a fused first trip;
     # k_regen: persistent waves, every lane walks one path to its end and then takes the next one (PBRT_FILM_REGEN): no path
     # state in memory, one launch per pass -- and still the same film, segments, shadow rays and per-depth path counts
-    for pp in (0, 3 * base.shape[0] * base.shape[1] + 5):
-        img = integ.render(sc, seed=5, spp=6, flags=capi.FILM_REGEN, pass_paths=pp)
-        st = ctx.stats()
-        assert np.array_equal(img, base), pp
+    walks = [dict(seed=5, spp=6, flags=capi.film_fuse_plan(plan) | capi.film_walk_from(walk))
+             for plan, walk in ((0x0, 0), (0x1, 0), (0x0, 1), (0x1, 2), (0x4, 2), (0x0, 3))]
+    regens = [dict(seed=5, spp=6, flags=capi.FILM_REGEN, pass_paths=pp) for pp in (0, 3 * base.shape[0] * base.shape[1] + 5)]
+    rs = diag_renders(mi, capi, scene, dict(spp=6, **kw), walks + regens)
+    for k, (img, st) in enumerate(rs):
+        assert np.array_equal(img, base), k
         assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
-        assert st["bounce_launches"] == st["passes"] and st["bounce_model_bytes"] == 12 * st["samples"]
+        if k >= len(walks):
+            assert st["bounce_launches"] == st["passes"] and st["bounce_model_bytes"] == 12 * st["samples"]
     # passes: a short last pass and the fused first launch
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)

@@ -3,7 +3,7 @@ restatement written from the reference's Python -- NOT from oracle/oracle.cpp (s
 
 Run in the build container (reads the reference's cbox OBJ quads as data):   python tests/golden/make_pinned.py
 Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k9_us_two_plates.npz, k9_us_two_plates_drjit.npz,
-                     k10_cbox_paths.npz, k11_meshes.npz
+                     k10_cbox_paths.npz, k11_meshes.npz, k12_emitter_sensor.npz
 
 K9  scenes:  'plate'       the scene USMain.py:26-90 builds (tilted plate 5 cm ahead, back wall at 1 m; integrator block :28-42)
              'sphere_box'  MitsubaScenes/Sphere_Box.xml:2-101 with the author-intent transforms
@@ -272,9 +272,50 @@ def make_k11():
           f"ball mean {Lb.mean():.5f}, lit {(Lb.sum(axis=3) > 0).mean() * 100:.1f} %")
 
 
+def make_k12():
+    """K12: CustomEmitter.sample_position / sample_ray (CustomEmmitter.py:30-107; linear array with the source's defaults, and the
+    convex branch :41-47) and UltraSensor.sample_ray (linear and convex, both direction branches) on seeded draws."""
+    rng = np.random.default_rng(12)
+    n = 512
+    out = {}
+    em_cases = {"linear": dict(number_of_elements=64, pitch=0.0003, element_width=0.0003, element_height=0.0005, radius=0.0,
+                               opening_angle=0.0, number_of_rays_per_element=1, speed_of_sound=1540.0, steering_angle_min=-10.0,
+                               steering_angle_max=10.0),
+                "convex": dict(number_of_elements=48, pitch=0.0003, element_width=0.0003, element_height=0.0005, radius=0.05,
+                               opening_angle=60.0, number_of_rays_per_element=4, speed_of_sound=1480.0, steering_angle_min=-15.0,
+                               steering_angle_max=5.0)}
+    draws = dict(time=rng.random(n) * 1e-6, s1=rng.random(n), s2=rng.random((n, 2)), s3=rng.random(n), wl=rng.random(n),
+                 pos=rng.random((n, 2)), ap=rng.random((n, 2)))
+    draws = {k: v.astype(np.float32).astype(np.float64) for k, v in draws.items()}   # the implementations take float32 inputs
+    for name, P in em_cases.items():
+        rec = np.array([np.concatenate([o, d, [t, w, pdf]]) for o, d, t, w, pdf in
+                        (rt.emitter_sample_ray(P, draws["time"][i], draws["s1"][i], draws["s2"][i], draws["s3"][i]) for i in range(n))])
+        out[f"emitter_{name}"] = rec
+    look = ([0.0, 0.0, 0.0], [0.1, 0.0, 1.0], [0.0, 1.0, 0.0])
+    T = rt.look_at(*look)
+    sn_cases = {"linear": dict(num_elements_lateral=64, element_width=0.003, element_height=0.01, pitch=3e-4, radius=math.inf,
+                               center_frequency=5e6, sound_speed=1540.0, directivity=1.0),
+                "convex": dict(num_elements_lateral=32, element_width=0.003, element_height=0.01, pitch=3e-4, radius=0.04,
+                               center_frequency=3e6, sound_speed=1540.0, directivity=0.7)}
+    for name, P in sn_cases.items():
+        for hemi in (1, 0):
+            rec = np.array([np.concatenate([o, d, [w]]) for o, d, w in
+                            (rt.ultra_sensor_sample_ray(P, T, draws["time"][i], draws["wl"][i], draws["pos"][i], draws["ap"][i], bool(hemi))
+                             for i in range(n))])
+            out[f"sensor_{name}_{hemi}"] = rec
+    meta = dict(emitters=em_cases, sensors={k: {kk: (None if isinstance(vv, float) and math.isinf(vv) else vv) for kk, vv in v.items()}
+                                            for k, v in sn_cases.items()}, look_at=look, n=n)
+    np.savez_compressed(os.path.join(HERE, "k12_emitter_sensor.npz"), meta=json.dumps(meta), **draws, **out)
+    print(f"k12_emitter_sensor.npz: {n} draws x {len(out)} cases")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "k12":
+        make_k12()
+        sys.exit(0)
     for name, S in US_SCENES.items():
         make_k9(name, S)
     make_k9("two_plates", US_SCENES["two_plates"], "drjit")      # simulate_acquisition (CustomIntegrator.py:60-232)
     make_k10()
     make_k11()
+    make_k12()

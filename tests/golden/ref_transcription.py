@@ -616,3 +616,79 @@ def shadow_clearance(shapes, light, o, d, dist):
                     u, v = (b1 * a22 - b2 * a12) / det, (b2 * a11 - b1 * a12) / det
                     m = min(m, abs(u), abs(v), abs(1.0 - u), abs(1.0 - v), abs(t - dist) / dist + (0.0 if 0 <= u <= 1 and 0 <= v <= 1 else 1.0))
     return m
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# SURVEY rows a13 / a14 -- the API-only leaf classes.  CustomEmitter from the reference's SOURCE (CustomEmmitter.py:30-107, line by
+# line); UltraSensor from SURVEY App. C (its source survives only as CPython-3.12 bytecode, read statically).  float64, the random
+# numbers are INPUTS.  dr.linspace(a, b, n)[i] = a + i (b - a) / (n - 1); mi.warp.square_to_uniform_hemisphere(s) =
+# (dx k, dy k, z) with (dx, dy) = concentric disk, z = 1 - |disk|^2, k = sqrt(z + 1)  (Mitsuba warp.h).
+# --------------------------------------------------------------------------------------------------------------------
+def emitter_element_geometry(P, i):
+    """CustomEmmitter.py:30-49 compute_element_geometry, element i -> (position, unit normal)"""
+    N = P["number_of_elements"]
+    if P["radius"] == 0.0:                                                     # :33
+        a, b = -(N - 1) / 2 * P["pitch"], (N - 1) / 2 * P["pitch"]              # :34-36
+        x = a + i * (b - a) / (N - 1) if N > 1 else a
+        pos, nrm = vec(x, 0.0, 0.0), vec(0.0, 0.0, 1.0)                         # :37-38
+    else:
+        span = math.radians(P["opening_angle"])                                # :42
+        th = -span / 2 + i * span / (N - 1) if N > 1 else -span / 2            # :43
+        pos = vec(P["radius"] * math.sin(th), 0.0, P["radius"] * math.cos(th))  # :44-46
+        nrm = vec(math.sin(th), 0.0, math.cos(th))                             # :47
+    return pos, normalize(nrm)                                                 # :49
+
+
+def emitter_sample_position(P, sample1, sample2):
+    """CustomEmmitter.py:51-79 -> (p, n, pdf)"""
+    N = P["number_of_elements"]
+    idx = int(min(math.floor(sample1 * N), N - 1))                             # :56-57
+    center, normal = emitter_element_geometry(P, idx)                          # :60-61
+    dx = (sample2[0] - 0.5) * P["element_width"]                               # :64
+    dy = (sample2[1] - 0.5) * P["element_height"]                              # :65
+    p = center + vec(dx, dy, 0.0)                                              # :68
+    pdf = 1.0 / (N * P["element_width"] * P["element_height"])                 # :77
+    return p, normal, pdf
+
+
+def emitter_sample_ray(P, time, sample1, sample2, sample3):
+    """CustomEmmitter.py:81-107 -> (o, d, ray time, weight, pdf_pos)"""
+    p, n, pdf = emitter_sample_position(P, sample1, sample2)                   # :82
+    psi_min, psi_max = math.radians(P["steering_angle_min"]), math.radians(P["steering_angle_max"])   # :85-86
+    psi = psi_min + sample3 * (psi_max - psi_min)                              # :87
+    d = vec(math.sin(psi), 0.0, math.cos(psi))                                 # :90
+    delta_t = time + (-(p[0] * math.sin(psi)) / P["speed_of_sound"])           # :93-94
+    fd = max(0.0, float(d @ n))                                                # :97
+    weight = fd / (P["number_of_elements"] * P["number_of_rays_per_element"])   # :17, :98
+    return p, d, delta_t, weight, pdf
+
+
+def square_to_uniform_hemisphere(sx, sy):
+    dx, dy = square_to_uniform_disk_concentric(sx, sy)
+    z = 1.0 - (dx * dx + dy * dy)
+    k = math.sqrt(z + 1.0)
+    return vec(dx * k, dy * k, z)
+
+
+def ultra_sensor_sample_ray(P, T, time, wavelength_sample, position_sample, aperture_sample, use_hemisphere_warp=True):
+    """SURVEY App. C, UltraSensor.sample_ray (bytecode src lines 37-90) -> (o, d, weight).  T: 4x4 to_world."""
+    N = P["num_elements_lateral"]
+    idx = min(math.floor(position_sample[0] * N), N - 1)
+    if math.isinf(P["radius"]):
+        ex, ez = -((N - 1) * P["pitch"]) / 2 + idx * P["pitch"], 0.0
+    else:
+        th = (idx - N / 2) * (P["pitch"] / P["radius"])
+        ex, ez = P["radius"] * math.sin(th), P["radius"] * (1.0 - math.cos(th))
+    ox = (aperture_sample[0] - 0.5) * P["element_width"]
+    oy = (aperture_sample[1] - 0.5) * P["element_height"]
+    o_local = vec(ex + ox, oy, ez)
+    if use_hemisphere_warp:
+        d_local = square_to_uniform_hemisphere(aperture_sample[0], aperture_sample[1])
+    else:
+        phi, ct = 2.0 * math.pi * position_sample[1], wavelength_sample
+        st = math.sqrt(max(0.0, 1.0 - ct * ct))
+        d_local = vec(st * math.cos(phi), st * math.sin(phi), ct)
+    o_world = T[:3, :3] @ o_local + T[:3, 3]
+    d_world = normalize(T[:3, :3] @ d_local)
+    weight = math.cos(2.0 * math.pi * P["center_frequency"] * time) * (abs(d_local[2]) * P["directivity"])
+    return o_world, d_world, weight

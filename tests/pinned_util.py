@@ -19,6 +19,41 @@ from conftest import GOLDEN
 SAFE = 1e-2
 
 
+def rng4(a, b, c, seed):
+    """the library's counter-based generator pcg4d(a, b, c, seed) -> four 24-bit uniforms (csrc/device_math.h rng4, oracle/omath.h),
+    restated on Python integers: what a test needs to build the inputs of a leaf operator without importing the generators of the
+    pinned fixtures (tests/golden/ref_transcription.py stays in the build container)"""
+    m = 0xFFFFFFFF
+    x, y, z, w = [(v * 1664525 + 1013904223) & m for v in (a, b, c, seed)]
+    x = (x + y * w) & m
+    y = (y + z * x) & m
+    z = (z + x * y) & m
+    w = (w + y * z) & m
+    x ^= x >> 16
+    y ^= y >> 16
+    z ^= z >> 16
+    w ^= w >> 16
+    x = (x + y * w) & m
+    y = (y + z * x) & m
+    z = (z + x * y) & m
+    w = (w + y * z) & m
+    return [(v >> 8) / 16777216.0 for v in (x, y, z, w)]
+
+
+def load_k12():
+    z = np.load(os.path.join(GOLDEN, "k12_emitter_sensor.npz"))
+    return z, json.loads(str(z["meta"]))
+
+
+def k12_emitter(mi, props):
+    return mi.CustomEmitter(mi.Properties("ultrasound_emitter", dict(props)))
+
+
+def k12_sensor(mi, props, look_at):
+    p = {k: (float("inf") if v is None else v) for k, v in props.items()}
+    return mi.UltraSensor(mi.Properties("ultrasound_sensor", dict(p, to_world=mi.ScalarTransform4f().look_at(*look_at))))
+
+
 def load_k9(name):
     z = np.load(os.path.join(GOLDEN, f"k9_us_{name}.npz"))
     return z, json.loads(str(z["meta"]))

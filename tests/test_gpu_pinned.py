@@ -103,3 +103,27 @@ def test_k9_hip_drjit_variant(mi, capi):
     assert ui.simulate_acquisition(sc) is True
     buf = ui.channel_buf.reshape(ui.n_angles, ui.n_elements, ui.time_samples)
     check_k9_bins(z, meta, buf, carrier=True)
+
+
+def test_k12_hip_emitter_and_sensor(mi):
+    """rows a13 / a14 on the device: CustomEmitter.sample_position / sample_ray and UltraSensor.sample_ray through the plugin API
+    against the float64 transcription of the reference (fixture K12; not through the oracle)."""
+    from pinned_util import load_k12, k12_emitter, k12_sensor
+    z, meta = load_k12()
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    t, s1, s2, s3, wl, pos, ap = (f32(z[k]) for k in ("time", "s1", "s2", "s3", "wl", "pos", "ap"))
+    for name, P in meta["emitters"].items():
+        e = k12_emitter(mi, P)
+        ray, w = e.sample_ray(t, s1, s2, s3)
+        want = z[f"emitter_{name}"]
+        assert np.allclose(ray["o"], want[:, 0:3], atol=1e-7) and np.allclose(ray["d"], want[:, 3:6], atol=1e-5)
+        assert np.allclose(ray["time"], want[:, 6], atol=1e-10, rtol=1e-5) and np.allclose(w, want[:, 7], atol=1e-5 * want[:, 7].max())
+        ps, pdf = e.sample_position(t, (s1, s2))
+        assert np.allclose(ps["p"], want[:, 0:3], atol=1e-7) and np.allclose(pdf, want[:, 8], rtol=1e-5)
+    for name, P in meta["sensors"].items():
+        sn = k12_sensor(mi, P, meta["look_at"])
+        for hemi in (1, 0):
+            ray, w = sn.sample_ray(t, wl, pos, ap, use_hemisphere_warp=bool(hemi))
+            want = z[f"sensor_{name}_{hemi}"]
+            assert np.allclose(ray["o"], want[:, 0:3], atol=1e-7) and np.allclose(ray["d"], want[:, 3:6], atol=1e-5)
+            assert np.allclose(w, want[:, 6], atol=2e-5)

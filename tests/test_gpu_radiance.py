@@ -172,11 +172,11 @@ def test_material_update_reaches_the_device(mi, ob):
 
 def _render_rays(mi, sc, seed, s_idx):
     """the camera rays of sample s_idx of every pixel, as render generates them: jitter = rng4(pixel, sample, 0, seed).xy
-    (the counter-based generator restated in tests/golden/ref_transcription.py), through Sensor.sample_ray"""
+    (the counter-based generator restated in tests/pinned_util.py), through Sensor.sample_ray"""
     import sys
     from conftest import GOLDEN
     sys.path.insert(0, GOLDEN)
-    import ref_transcription as rt
+    import pinned_util as rt
     sens = sc.sensors()[0]
     W, H = sens.film().size()
     jit = np.array([rt.rng4(p, s_idx, 0, seed)[:2] for p in range(W * H)], np.float32)

@@ -176,3 +176,19 @@ def test_meshes_with_vertex_normals(mi, ob, capi, tmp_path, n_lat, n_lon, accel)
     want, _ = ob.OracleScene.from_scene(us).us_acquire(ui.us_params(us), 2, 80)
     rel = np.linalg.norm(ui.channel_buf.astype(np.float64) - want) / np.linalg.norm(want.astype(np.float64))
     assert rel <= 1e-3 and np.array_equal(ui.channel_buf != 0, want != 0) and np.abs(want).max() > 0
+
+
+def test_the_references_bunny_on_the_device(mi, ob, capi):
+    """scenes/meshes/bunny.ply of the reference (binary little-endian PLY, 69 451 triangles; committed as a
+    data asset) through the BVH that does not fit LDS -- k_trace / k_shade with the tree read through the vector caches -- bit for
+    bit the oracle's film (its own median-split tree: the result does not depend on the tree), and the same film at another pass
+    size."""
+    sc = mi.load_file(scene_path("bunny.xml"), res=64, spp=4)
+    assert len(sc.flatten()["prims"]) == 69451 + 2
+    integ = sc.integrator()
+    img = integ.render(sc, seed=11, spp=4)
+    st = mi.default_context().stats()
+    ref, _ = oracle_render(ob, sc, 11, 4)
+    assert np.array_equal(img, ref) and img.mean() > 0.05
+    assert st["plan_source"] == capi.PLAN_STREAMS and st["live"][0] == 64 * 64 * 4 and 0 < st["live"][1] < st["live"][0]
+    assert np.array_equal(integ.render(sc, seed=11, spp=4, pass_paths=5000), img)

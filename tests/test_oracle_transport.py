@@ -209,7 +209,7 @@ def test_integrator_sample_twin_equals_the_film(mi, ob):
     import sys
     from conftest import GOLDEN
     sys.path.insert(0, GOLDEN)
-    import ref_transcription as rt
+    import pinned_util as rt
     sc = mi.load_file(scene_path("cbox.xml"), res=20, spp=1, rfilter="box")
     integ, sens = sc.integrator(), sc.sensors()[0]
     W = H = 20

@@ -131,3 +131,26 @@ def test_k9_oracle_drjit_variant(mi, ob, capi):
     # it is a different estimator from the scalar variant's: second-bounce echoes land elsewhere (tof is not accumulated)
     zs, _ = load_k9("two_plates")
     assert not np.array_equal(z["bin_index"], zs["bin_index"]) and int(meta["deposited_by_depth"]["1"]) >= 100
+
+
+def test_k12_emitter_and_sensor_oracle(mi, ob):
+    """rows a13 / a14: the oracle's CustomEmitter.sample_ray / sample_position and UltraSensor.sample_ray against the float64
+    transcription of CustomEmmitter.py:30-107 (linear array and the convex branch :41-47: steering delay -x sin(psi) / c, weight
+    max(0, d.n) / N_rays) and of SURVEY App. C -- code that shares no source text with oracle.cpp.  1e-5."""
+    from pinned_util import load_k12, k12_emitter, k12_sensor
+    z, meta = load_k12()
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    t, s1, s2, s3, wl, pos, ap = (f32(z[k]) for k in ("time", "s1", "s2", "s3", "wl", "pos", "ap"))
+    for name, P in meta["emitters"].items():
+        e = k12_emitter(mi, P)
+        o, d, rt_, w, pdf = ob.us_emitter_sample_ray(e._desc(), t, s1, s2, s3)
+        want = z[f"emitter_{name}"]
+        assert np.allclose(o, want[:, 0:3], atol=1e-7) and np.allclose(d, want[:, 3:6], atol=1e-5)
+        assert np.allclose(rt_, want[:, 6], atol=1e-10, rtol=1e-5) and np.allclose(w, want[:, 7], atol=1e-5 * want[:, 7].max())
+        assert np.allclose(pdf, want[:, 8], rtol=1e-5)
+    for name, P in meta["sensors"].items():
+        sn = k12_sensor(mi, P, meta["look_at"])
+        for hemi in (1, 0):
+            o, d, w = ob.us_sensor_sample_ray(sn._desc(), hemi, t, wl, pos, ap)
+            want = z[f"sensor_{name}_{hemi}"]
+            assert np.allclose(o, want[:, 0:3], atol=1e-7) and np.allclose(d, want[:, 3:6], atol=1e-5) and np.allclose(w, want[:, 6], atol=2e-5)

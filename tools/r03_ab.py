@@ -7,12 +7,21 @@ import hashlib, os, sys
 sys.path.insert(0, %r)
 import pbrt_amd as mi
 scene, res, spp = os.environ.get("AB_SCENE", "tests/scenes/testring.xml"), int(os.environ.get("AB_RES", "1024")), int(os.environ.get("AB_SPP", "64"))
+if os.environ.get("AB_MODE") == "us":   # BASELINE config 3: the Sphere_Box phantom, 5 x 64 rays x 838 912 paths
+    import numpy as np
+    us = mi.load_file(os.path.join(%r, "tests/scenes/us_sphere_box.xml"))
+    ui = us.integrator()
+    best = 1e9
+    for i in range(int(os.environ.get("AB_REPS", "3"))):
+        buf = ui._acquire(us, ui.quirks, paths_per_ray=838912, seed=0); st = mi.default_context().stats(); best = min(best, st["kernel_ms"])
+    print(f"{best:8.2f} ms  {st['samples']/best/1e3:7.0f} Msamples/s  |buf| {float(np.abs(buf).sum()):.9g} nonzero {int((buf != 0).sum())}", flush=True)
+    sys.exit(0)
 sc = mi.load_file(os.path.join(%r, scene), res=res, spp=spp)
 best = 1e9
 for i in range(int(os.environ.get("AB_REPS", "3"))):
     img = mi.render(sc, seed=0); st = mi.default_context().stats(); best = min(best, st["kernel_ms"])
 print(f"{best:8.2f} ms  {res*res*spp/best/1e3:7.0f} Msamples/s  film {hashlib.sha256(img.tobytes()).hexdigest()[:12]}", flush=True)
-''' % (ROOT, ROOT)
+''' % (ROOT, ROOT, ROOT)
 for rnd in range(int(os.environ.get("AB_ROUNDS", "1"))):
     for spec in sys.argv[1:]:
         name, rest = spec.split("=", 1)

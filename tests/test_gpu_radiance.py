@@ -404,3 +404,20 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
             assert st["bounce_launches"] == st["passes"] and st["bounce_model_bytes"] == 12 * st["samples"]
     # passes: a short last pass and the fused first launch
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)
+
+
+def test_render_larger_than_a_pass_with_an_odd_pixel_count(mi, ob, capi):
+    """more samples than the 64 Mi paths of a pass, on a film whose pixel count divides nothing: 521 x 521 x 256 = 69.5 M samples run
+    as two equal passes of 128 spp; a band of the film equals the oracle's render of that crop (the crop render redoes the halo rows).
+    With the plan that walks every bounce in one launch no path state is allocated: the workspace stays far below the 8 GB the
+    ping-pong state of 64 Mi paths would take."""
+    sc = mi.load_file(scene_path("cbox.xml"), res=521, spp=256)
+    integ = sc.integrator()
+    img = integ.render(sc, seed=4, spp=256, flags=capi.film_fuse_plan(0x3F))
+    st = mi.default_context().stats()
+    H, W = img.shape[:2]
+    assert st["samples"] == W * H * 256 > (64 << 20) and st["passes"] == 2 and st["pass_paths"] == W * H * 128
+    assert st["bounce_launches"] == 2 and st["workspace_bytes"] < 3 * 10**9
+    y0 = H // 2
+    ref, _ = oracle_render(ob, sc, 4, 256, crop=(0, y0, W, 8))
+    assert np.array_equal(img[y0:y0 + 8], ref)

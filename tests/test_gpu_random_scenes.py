@@ -192,3 +192,14 @@ def test_the_references_bunny_on_the_device(mi, ob, capi):
     assert np.array_equal(img, ref) and img.mean() > 0.05
     assert st["plan_source"] == capi.PLAN_STREAMS and st["live"][0] == 64 * 64 * 4 and 0 < st["live"][1] < st["live"][0]
     assert np.array_equal(integ.render(sc, seed=11, spp=4, pass_paths=5000), img)
+
+
+def test_the_references_suzanne_with_its_vertex_normals(mi, ob, capi):
+    """scenes/meshes/suzanne.ply of the reference (62 976 triangles, PLY normals + texture coordinates): the interpolated shading
+    normals of Mitsuba's Mesh on a mesh larger than LDS, bit for bit the oracle's film"""
+    sc = mi.load_file(scene_path("suzanne.xml"), res=64, spp=4)
+    f = sc.flatten()
+    assert len(f["prims"]) == 62976 + 2 and f["vertex_normals"] is not None
+    img = sc.integrator().render(sc, seed=12, spp=4)
+    ref, _ = oracle_render(ob, sc, 12, 4)
+    assert np.array_equal(img, ref) and img.mean() > 0.05

@@ -34,9 +34,12 @@ def per_dispatch(sub, ctr):
             if r["Counter_Name"] == ctr and any(k + "<" in r["Kernel_Name"] for k in families)]
     # the first render of a brute-force scene starts with a 2-spp probe pass (the library learns its launch plan from it): those
     # small launches are not the workload -- keep the dispatches of the full-size grid only
-    gmax = max((int(r["Grid_Size"]) for r in rows), default=0)
+    fam = lambda r: r["Kernel_Name"].split("<")[0]   # (k_trace and k_shade have grids of their own)
+    gmax = {}
     for r in rows:
-        if int(r["Grid_Size"]) * 2 < gmax:
+        gmax[fam(r)] = max(gmax.get(fam(r), 0), int(r["Grid_Size"]))
+    for r in rows:
+        if int(r["Grid_Size"]) * 2 < gmax[fam(r)]:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])

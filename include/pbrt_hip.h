@@ -103,9 +103,9 @@ typedef struct pbrt_emitter {
 
 #define PBRT_ACCEL_AUTO 0u  /* brute force when n_prims <= 32, LDS-resident BVH otherwise */
 #define PBRT_ACCEL_BRUTE 1u /* uniform loop over all primitives (scalar loads)            */
-#define PBRT_ACCEL_BVH 2u   /* BVH2, nodes + primitives staged into LDS per workgroup (read through the vector caches
-                               when the image does not fit the 160 KB of LDS)                */
-#define PBRT_ACCEL_BVH_GLOBAL 3u /* BVH2 read through the vector caches even if it would fit LDS (the kernel variant of
+#define PBRT_ACCEL_BVH 2u   /* BVH4 (child boxes on an 8-bit grid, 40-byte leaf records), nodes + leaf records staged into LDS per
+                               workgroup (read through the vector caches when the image does not fit the 160 KB of LDS)   */
+#define PBRT_ACCEL_BVH_GLOBAL 3u /* BVH4 read through the vector caches even if it would fit LDS (the kernel variant of
                                large meshes, forced: for tests and A/B runs)                 */
 
 typedef struct pbrt_scene_desc {
@@ -151,13 +151,16 @@ typedef struct pbrt_film_desc {
     uint32_t filter;                         /* PBRT_FILTER_*                            */
     uint32_t seed;
     uint32_t flags;      /* PBRT_FILM_*                                                  */
-    uint32_t pass_paths; /* 0 = library default; paths kept in flight per pass           */
+    uint32_t pass_paths; /* 0 = library default; paths kept in flight per pass.  Default: 64 Mi for brute-force scenes
+                            (8 B..120 B of workspace per path, by launch plan); BVH scenes (356 B per path) the largest power of
+                            two, 16 .. 256 Mi, whose workspace fits 40 % of the free device memory -- pbrt_stats reports both */
 } pbrt_film_desc;
 
 #define PBRT_FILM_RAW_ACCUM 1u /* output 4 floats/pixel (sum w*rgb, sum w) un-normalised: \
                                   for sample-sharded multi-GPU reduction */
-#define PBRT_FILM_NO_REPACK 2u /* diagnostic: BVH scenes, do not re-densify the live paths before bounces >= 2 \
-                                  (same image either way) */
+/* The flags marked DIAGNOSTIC BUILD select launch structures that lost their A/B: the product library does not carry their kernels
+ * and refuses them with PBRT_E_UNSUPPORTED; libpbrt_hip_diag.so (make -C csrc diag, -DPBRT_DIAG) has them.  Same film either way. */
+#define PBRT_FILM_NO_REPACK 2u /* DIAGNOSTIC BUILD, with PBRT_FILM_NO_HIT_POOL: do not re-densify the live paths before bounces >= 2 */
 #define PBRT_FILM_FUSE_PLAN_SET 0x80u /* bits 8..15 of flags hold the fuse plan: bit d set = the launch that walks bounce d goes on \
                                         with bounce d + 1 of its paths in registers, up to 6 bounces per launch (brute-force \
                                         kernels; same film whatever the plan).  PBRT_FILM_FUSE_PLAN(0) = one launch per bounce, \
@@ -165,14 +168,14 @@ typedef struct pbrt_film_desc {
                                         paths survive each bounce (it goes on while >= 45 % do) -- measured on a 2-spp probe \
                                         pass at the start of the first render of a scene, afterwards on the scene's last render */
 #define PBRT_FILM_FUSE_PLAN(mask) (PBRT_FILM_FUSE_PLAN_SET | (((mask) & 0xffu) << 8))
-#define PBRT_FILM_WALK_SET 0x10000u /* bits 17..24 of flags hold the depth from which ONE launch walks every remaining bounce of a \
-                                       pass (brute-force kernels: the workgroup that owns a segment carries its survivors on; \
-                                       0 = one launch per pass, 0xff = never).  Unset: the library's default.  Same film either way */
+#define PBRT_FILM_WALK_SET 0x10000u /* DIAGNOSTIC BUILD: bits 17..24 of flags hold the depth from which ONE launch walks every remaining \
+                                       bounce of a pass (k_walk, brute-force kernels: the workgroup that owns a segment carries its \
+                                       survivors on; 0 = one launch per pass, 0xff = never) */
 #define PBRT_FILM_WALK_FROM(d) (PBRT_FILM_WALK_SET | (((d) & 0xffu) << 17))
-#define PBRT_FILM_REGEN 8u /* diagnostic: brute-force scenes, persistent waves with path regeneration (k_regen: no path state in \
-                             memory, one launch per pass; same film, measured slower than the wavefront launches) */
-#define PBRT_FILM_NO_HIT_POOL 0x10u /* diagnostic: BVH scenes, bounces >= 1 through k_bounce (shading in whatever lanes are left after the \
-                                    closest hit) instead of k_bounce_pool (closest hits first, shading in full waves) */
+#define PBRT_FILM_REGEN 8u /* DIAGNOSTIC BUILD: brute-force scenes, persistent waves with path regeneration (k_regen: no path state in \
+                             memory, one launch per pass; measured slower than the wavefront launches) */
+#define PBRT_FILM_NO_HIT_POOL 0x10u /* DIAGNOSTIC BUILD: BVH scenes through the fused bounce kernel (closest hit, shading and shadow ray in \
+                                    one launch per bounce, 4 waves per SIMD) instead of k_trace + k_shade (kernels_wavefront.h) */
 #define PBRT_FILM_NO_OCCLUDER_PRUNING 4u /* diagnostic: next-event shadow segments of brute-force scenes walk EVERY primitive \
                                            instead of the occluder list (DESIGN D11: primitives on the scene's convex hull \
                                            and the lone area light are left out of it) -- same film if the pruning is right */

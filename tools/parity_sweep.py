@@ -40,14 +40,22 @@ for k in range(n):
         variants += [("no_pool", capi.FILM_NO_HIT_POOL, None), ("no_repack", capi.FILM_NO_REPACK, None), ("global", 0, capi.ACCEL_BVH_GLOBAL),
                      ("global_no_pool", capi.FILM_NO_HIT_POOL, capi.ACCEL_BVH_GLOBAL)]
     res = []
+    DIAG_FLAGS = capi.FILM_REGEN | capi.FILM_NO_HIT_POOL | capi.FILM_NO_REPACK | capi.FILM_WALK_SET
     for name, fl, acc in variants:
-        s2 = sc
-        if acc is not None:
-            s2 = _random_scene(mi, tmp, seed, ns, nr, nt, nc)
-            s2.accel = acc
-            s2.integrator().max_depth = integ.max_depth
-            set_film(s2)
-        img = s2.integrator().render(s2, seed=seed, spp=spp, flags=fl, pass_paths=(0 if k % 2 else 96 * 64 * 4 + 11))
+        import contextlib
+        # launch structures of the diagnostic build (libpbrt_hip_diag.so): a fresh scene bound to that library's context
+        diag = bool(fl & DIAG_FLAGS)
+        with (capi.use_library(capi.DIAG_LIB_PATH) if diag else contextlib.nullcontext()):
+            s2 = sc
+            if acc is not None or diag:
+                s2 = _random_scene(mi, tmp, seed, ns, nr, nt, nc)
+                if acc is not None:
+                    s2.accel = acc
+                s2.integrator().max_depth = integ.max_depth
+                set_film(s2)
+            img = s2.integrator().render(s2, seed=seed, spp=spp, flags=fl, pass_paths=(0 if k % 2 else 96 * 64 * 4 + 11))
+            if diag:
+                s2._dev = None
         ok = bool(np.array_equal(img, ref))
         bad += not ok
         res.append(f"{name}:{'ok' if ok else 'DIFF'}")

@@ -121,6 +121,7 @@ struct RadArgs {
     uint32_t n_paths;  // paths generated by the first bounce of this pass
     uint32_t depth, max_depth, rr_depth, seed;
     uint32_t nb;  // bounces this launch walks (the multi-bounce variants k_bounce<.., 2>; 2 .. MAX_CHAIN)
+    uint32_t merge_at;  // k_chain_pair: the bounce from which a wave walks the survivors of its two tiles together (1 .. max_depth - 1)
     // key mode 0 (render): home -> (region pixel, local sample)
     uint32_t key_mode;
     uint32_t rx0, ry0, rw, npix_r, s_first, film_w, film_h;
@@ -683,6 +684,144 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
 }
 
 #ifdef PBRT_DIAG  // launch structures that lost their A/B: kept for the diagnostic build only (make diag)
+// ---- k_chain_pair: the whole path in one launch, TWO 64-path tiles per wave ---------------------------------------------------
+// A chain launch keeps a wave busy until the longest of its 64 paths has ended: in the Cornell box 100 / 87 / 67 / 56 / 47 / 9 % of
+// the lanes carry a path at bounces 0 .. 5, and a bounce costs a wave the same whether 64 or 6 of its lanes are live.  Here a wave
+// walks tile A up to bounce a.merge_at, parks the survivors in a wave-private LDS strip (N_STATE dwords each, packed), walks tile B
+// up to the same bounce, deals the parked paths to B's idle lanes and walks the rest of both tiles ONCE.  Parked paths that find no
+// idle lane (more than 64 survivors in the pair) are walked afterwards in a turn of their own.  Every path does the arithmetic it
+// did before with the same RNG keys (path_key of its home), so the film does not change.  The strip is only touched by its own wave:
+// LDS operations of one wave complete in order, no barrier.
+// Measured (Cornell box 512^2 x 256, one launch per pass): k_bounce chain 6.02 - 6.07 ms; this kernel with merge bounce 3 / 4 / 5:
+// 6.37 / 6.43 - 6.55 / 6.48 ms.  Merging at bounce 5 merges nothing that costs (the last bounce only looks for emitters), so 6.48 is
+// the price of the structure itself (12 spilled VGPRs and 50 spilled SGPRs at the 64-register budget, against 1 and 13), and the
+// merge buys 0.1 ms of the 0.6 - 0.8 ms that the count of wave-bounces promises: a wave with half of its lanes idle skips the
+// branches that none of its paths takes, a full wave of paths from two tiles takes them all.  Diagnostic build only
+// (PBRT_PAIR_MERGE=k picks the merge bounce).
+// Host: max_depth <= MAX_CHAIN (every path ends inside the launch: no state goes out), 1 <= merge_at < max_depth,
+// grid = ceil(n_paths / (2 * SEG_BRUTE)).
+template <int ACCEL>
+__global__ __launch_bounds__(SEG_BRUTE, ACCEL == ACCEL_K_BRUTE ? FUSED_WAVES_PER_EU : BIG_WAVES_PER_EU) void k_chain_pair(const RadArgs a) {
+    static_assert(ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG, "k_chain_pair: brute-force kernels");
+    constexpr uint32_t SEG = SEG_BRUTE, W = SEG / 64;
+    __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
+    __shared__ uint32_t park[W][N_STATE][64];
+    __shared__ uint32_t wave_cnt[W][2 + MAX_CHAIN];  // per wave: segments, shadow rays, paths entering bounce b (lane 0 adds)
+    const uint32_t region = xcd_swizzle(blockIdx.x, gridDim.x);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
+    const LdsScene ls = NO_LDS_SCENE;
+    const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
+    if (ACCEL == ACCEL_K_BRUTE) fill_tables_lds(a.sc, tab_lds, SEG);  // ends with a barrier
+    const Rsrc r_L = make_rsrc(a.Lhome, a.cap * 16u);
+    uint32_t(*pk)[64] = park[wid];
+    const uint32_t tile0 = (region * W + wid) * 2u;
+    const uint32_t m = a.merge_at;
+    // four turns (wave-uniform): 0 = tile A up to the merge bounce, 1 = tile B likewise, 2 = both from there on, 3 = parked paths
+    // that found no lane
+    uint32_t n_park = 0, left0 = 0, n_left = 0;
+    if (lane < 2u + MAX_CHAIN) wave_cnt[wid][lane] = 0u;
+    V3 o = {0, 0, 0}, d = {0, 0, 1}, thr = {0, 0, 0}, L = {0, 0, 0};
+    float eta = 1.0f, prev_pdf = -1.0f, tmax = K_INF;
+    uint32_t home = 0, ka = 0, kb = 0;
+    bool live = false;
+#pragma unroll 1
+    for (uint32_t turn = 0; turn < 4u; ++turn) {
+        uint32_t b_first = 0, b_end = m;
+        if (turn < 2u) {  // the camera paths of the tile
+            const uint32_t slot = (tile0 + turn) * 64u + lane;
+            live = slot < a.n_paths;
+            home = slot;
+            if (live) {
+                uint32_t px, py;
+                path_key<true>(a, home, &ka, &kb, &px, &py);
+                F4 uj = rng4(ka, kb, 0, a.seed);
+                float fx = (float)px + uj.x, fy = (float)py + uj.y;
+                camera_ray(a.cam, fx / (float)a.film_w, fy / (float)a.film_h, &o, &d, &tmax);
+                thr = {1, 1, 1};
+                L = {0, 0, 0};
+                eta = 1.0f;
+                prev_pdf = -1.0f;
+            }
+        } else {
+            // turn 2: the parked paths go to the idle lanes of tile B, in order; turn 3: those that found none, from lane 0 on
+            // (every lane is idle by then)
+            if (turn == 3u && n_left == 0u) break;
+            const unsigned long long idle = ~__ballot(live);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            uint32_t n_take;
+            if (turn == 2u) {
+                n_take = min(n_park, (uint32_t)__popcll(idle));
+                left0 = n_take;
+                n_left = n_park - n_take;
+            } else {
+                n_take = n_left;
+            }
+            const uint32_t r = (turn == 2u ? 0u : left0) + rank;
+            if (!live && rank < n_take) {
+                o = {__uint_as_float(pk[0][r]), __uint_as_float(pk[1][r]), __uint_as_float(pk[2][r])};
+                d = {__uint_as_float(pk[3][r]), __uint_as_float(pk[4][r]), __uint_as_float(pk[5][r])};
+                thr = {__uint_as_float(pk[6][r]), __uint_as_float(pk[7][r]), __uint_as_float(pk[8][r])};
+                L = {__uint_as_float(pk[9][r]), __uint_as_float(pk[10][r]), __uint_as_float(pk[11][r])};
+                eta = __uint_as_float(pk[12][r]);
+                prev_pdf = __uint_as_float(pk[13][r]);
+                home = pk[14][r];
+                uint32_t px, py;
+                path_key<true>(a, home, &ka, &kb, &px, &py);
+                live = true;
+            }
+            b_first = m;
+            b_end = a.max_depth;
+        }
+#pragma unroll 1
+        for (uint32_t bounce = b_first; bounce < b_end; ++bounce) {
+            const uint32_t n_on = (uint32_t)__popcll(__ballot(live));
+            if (n_on == 0u) break;
+            if (lane == 0u) atomicAdd(&wave_cnt[wid][2u + bounce], n_on);
+            if (bounce > 0u) tmax = K_INF;
+            bool did_seg = false, did_shadow = false, survive = false;
+            if (live) survive = bounce_step<ACCEL>(a, tb, ls, r_L, bounce, ka, kb, home, tmax, o, d, thr, L, eta, prev_pdf, did_seg, did_shadow);
+            live = survive;
+            const uint32_t n_sg = (uint32_t)__popcll(__ballot(did_seg)), n_sh = (uint32_t)__popcll(__ballot(did_shadow));
+            if (lane == 0u) {
+                atomicAdd(&wave_cnt[wid][0], n_sg);
+                atomicAdd(&wave_cnt[wid][1], n_sh);
+            }
+        }
+        if (turn == 0u) {  // park the survivors of tile A
+            const unsigned long long bal = __ballot(live);
+            n_park = (uint32_t)__popcll(bal);
+            if (live) {
+                const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                pk[0][k] = __float_as_uint(o.x);
+                pk[1][k] = __float_as_uint(o.y);
+                pk[2][k] = __float_as_uint(o.z);
+                pk[3][k] = __float_as_uint(d.x);
+                pk[4][k] = __float_as_uint(d.y);
+                pk[5][k] = __float_as_uint(d.z);
+                pk[6][k] = __float_as_uint(thr.x);
+                pk[7][k] = __float_as_uint(thr.y);
+                pk[8][k] = __float_as_uint(thr.z);
+                pk[9][k] = __float_as_uint(L.x);
+                pk[10][k] = __float_as_uint(L.y);
+                pk[11][k] = __float_as_uint(L.z);
+                pk[12][k] = __float_as_uint(eta);
+                pk[13][k] = __float_as_uint(prev_pdf);
+                pk[14][k] = home;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long *row = a.stats + region;
+        const size_t stride = a.stat_stride;
+        for (uint32_t k = 0; k < 2u + a.max_depth; ++k) {
+            uint32_t n = 0;
+            for (uint32_t w = 0; w < W; ++w) n += wave_cnt[w][k];
+            row[k * stride] += n;
+        }
+    }
+}
+
 // ---- k_walk: ONE launch walks every remaining bounce (brute-force kernels) -----------------------------------------------
 // Compaction is local to the segment, so nothing forces a grid-wide barrier between bounces: the workgroup that owns a
 // segment carries its survivors from bounce to bounce on its own, ping-ponging between the two state buffers (release

@@ -60,7 +60,8 @@ struct WfArgs {
     const uint32_t *seg_in, *nsh_in;   // per region: live paths; shadow rays of the previous bounce (survivors' | ended paths' << 16)
     uint32_t *seg_out, *nsh_out;       // (nsh_in: nullptr at depth 0)
     unsigned long long *stats;   // per-region rows as in RadArgs
-    uint32_t stat_stride, cap, n_paths, n_regions;
+    uint32_t stat_stride, cap, n_paths, n_regions;  // n_regions: regions of THIS launch, the first one is region0
+    uint32_t region0;
     uint32_t depth, max_depth, rr_depth, seed;
     uint32_t key_mode, rx0, ry0, rw, npix_r, s_first, film_w, film_h, tile_rows;
     FastDiv div_npix, div_rw;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     if (tid == 0) {
         uint32_t run = 0;
         for (uint32_t j = 0; j < K; ++j) {
-            const uint32_t r = blockIdx.x + j * G, b = r * WF_REGION;
+            const uint32_t r = a.region0 + blockIdx.x + j * G, b = r * WF_REGION;
             const uint32_t ns = (!FIRST && a.nsh_in) ? a.nsh_in[r] : 0u;
             cum[3 * j] = run;
             seg0[3 * j] = b | WF_SHADOW;
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
     __shared__ uint32_t wlist[W][128], wprim[W][128];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
-    const uint32_t r = xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
+    const uint32_t r = a.region0 + xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wid = tid >> 6;
     const uint32_t cnt_in = FIRST ? (a.n_paths > base ? min(a.n_paths - base, WF_REGION) : 0u) : a.seg_in[r];
     const uint32_t n_dead = (!FIRST && a.nsh_in) ? a.nsh_in[r] >> 16 : 0u;

@@ -27,6 +27,8 @@ struct pbrt_ctx {
     int device = 0;
     int n_cu = 256;  // compute units (MI355X: 256); read from the device properties
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;          // BVH scenes: the second half of a pass's regions (wf_bounces)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     pbrt_stats stats{};
     std::map<std::string, DevBuf> ws;  // grow-only workspace
@@ -257,11 +259,15 @@ int pbrt_ctx_destroy(pbrt_ctx *c) {
     if (!c) return PBRT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto &kv : c->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBRT_OK;
@@ -515,6 +521,17 @@ static uint32_t plan_from_survival(const unsigned long long *live, uint32_t max_
     return plan;
 }
 
+// k_chain_pair (two tiles per wave, kernels_radiance.h; lost its A/B): diagnostic builds launch it instead of the k_bounce chain
+// when PBRT_PAIR_MERGE=k names the merge bounce and the plan walks the whole path in one launch.
+#ifdef PBRT_DIAG
+static uint32_t pair_merge_bounce(uint32_t plan, uint32_t max_depth) {
+    const char *e = getenv("PBRT_PAIR_MERGE");  // (read per pass: a test switches it between renders)
+    if (!e || max_depth > MAX_CHAIN || max_depth < 2 || chain_len(plan, 0, max_depth) < max_depth) return 0;
+    const uint32_t k = (uint32_t)atoi(e);
+    return k < max_depth ? k : 0u;
+}
+#endif
+
 // Byte model of the radiance path (DESIGN.md "Algorithmic bytes").  live[d] = paths entering depth d.
 // A launch that walks two bounces (fuse plan bit d) keeps its paths in registers between them: the survivors of bounce d
 // are neither written nor read back, only the survivors of bounce d + 1 are.
@@ -543,6 +560,7 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
 
 // ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
 struct WfPlan {
+    uint32_t streams = 1;    // PBRT_WF_STREAMS=2: the halves of a pass on two streams, one phase apart (measured +2.8 %: DESIGN.md section 7)
     uint32_t grid_deep = 2;  // workgroups per CU from bounce 2 on (few rays: a resident round of larger shares; ring 8 / 2 / 1: 139.7 / 137.1 / 134.9 ms)
     uint32_t threads = 1024, rows = 2, grid_mult = 8;  // grid: ring 1024^2 x 64: 2 / 4 / 8 / 16 workgroups per CU -> 27.6 / 21.3 / 20.4 / 21.3 ms
     size_t lds = 0;
@@ -568,6 +586,8 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     if (e_grid) p.grid_mult = std::max(1u, (uint32_t)atoi(e_grid));
     static const char *e_deep = getenv("PBRT_WF_GRID_DEEP");
     if (e_deep) p.grid_deep = std::max(1u, (uint32_t)atoi(e_deep));
+    static const char *e_str = getenv("PBRT_WF_STREAMS");
+    if (e_str) p.streams = std::max(1u, (uint32_t)atoi(e_str));
     p.lds = (size_t)image + (size_t)p.rows * p.threads * 4u;
     return p;
 }
@@ -603,20 +623,29 @@ static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
 // Returns the number of launches through *launches.
 static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p, uint32_t nreg, bool camera, uint32_t *launches) {
     pbrt_ctx *c = s->ctx;
-    hipStream_t st = c->stream;
     const bool lds = s->accel_kernel == ACCEL_K_BVH_LDS;
-    const uint32_t G0 = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_mult * (uint32_t)c->n_cu));
-    const uint32_t G2 = std::min(nreg, std::max(div_up(nreg, WF_KMAX), p.grid_deep * (uint32_t)c->n_cu));
-    a.n_regions = nreg;
     a.lds_bytes = lds ? s->lds_bytes : 0u;
     a.stk_rows = p.rows;
     a.stk_shift = 0;
     while ((1u << a.stk_shift) < p.threads) ++a.stk_shift;
     // the small shading tables in LDS when they fit (kernels_wavefront.h wf_tables_lds)
     const bool tabs = s->ds.n_mats <= TAB_MAX && s->ds.n_emitters <= TAB_MAX && s->ds.n_light_prims <= TAB_MAX;
+    // Opt-in (PBRT_WF_STREAMS=2): the two halves of the pass's regions on two streams, the second one phase behind the first, so
+    // that one half's shading (HBM-bound) runs beside the other half's tracing (VALU-bound).  Regions are independent (their own
+    // slots of every buffer, their own statistics rows), so the halves share nothing.  Measured gain 2.8 %: k_trace holds all
+    // eight wave slots of a SIMD, so a k_shade workgroup only gets onto a CU in place of a k_trace workgroup.
+    const bool two = p.streams >= 2 && nreg >= 256 && a.max_depth <= 32;
+    if (two && !c->stream2) {
+        HIPCHK(c, hipStreamCreate(&c->stream2));
+        HIPCHK(c, hipEventCreate(&c->ev_fork));
+        HIPCHK(c, hipEventCreate(&c->ev_join));
+    }
+    const uint32_t n_half = two ? 2u : 1u;
+    const uint32_t reg0[2] = {0u, two ? nreg / 2u : 0u}, regn[2] = {two ? nreg / 2u : nreg, two ? nreg - nreg / 2u : 0u};
+    hipStream_t strm[2] = {c->stream, two ? c->stream2 : c->stream};
     float4 *in = b.stA, *out = b.stB, *shi = b.shA, *sho = b.shB;
     uint32_t *sin = b.segA, *sout = b.segB, *ni = b.nshA, *no = b.nshB;
-    auto one = [&](uint32_t depth, bool first, bool have_shadows) {
+    auto fill = [&](uint32_t depth, bool have_shadows, uint32_t h) {
         a.depth = depth;
         a.st_in = in;
         a.st_out = out;
@@ -628,27 +657,46 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         a.seg_out = sout;
         a.nsh_in = have_shadows ? ni : nullptr;
         a.nsh_out = no;
-        const uint32_t G = depth >= 2 ? G2 : G0;
+        a.region0 = reg0[h];
+        a.n_regions = regn[h];
+    };
+    auto trace = [&](uint32_t depth, bool first, bool have_shadows, uint32_t h) {
+        fill(depth, have_shadows, h);
+        const uint32_t nr = regn[h];
+        const uint32_t mult = depth >= 2 ? p.grid_deep : p.grid_mult;
+        const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * (uint32_t)c->n_cu / n_half)));
+        hipStream_t st = strm[h];
         if (first) {
             if (lds)
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
             else
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
-            if (tabs)
-                hipLaunchKernelGGL((k_shade<true, true>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
-            else
-                hipLaunchKernelGGL((k_shade<true, false>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
         } else {
             if (lds)
                 hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
             else
                 hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
-            if (tabs)
-                hipLaunchKernelGGL((k_shade<false, true>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
-            else
-                hipLaunchKernelGGL((k_shade<false, false>), dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, a);
         }
-        *launches += 2;
+        ++*launches;
+    };
+    auto shade = [&](uint32_t depth, bool first, bool have_shadows, uint32_t h) {
+        fill(depth, have_shadows, h);
+        hipStream_t st = strm[h];
+        const dim3 g(regn[h]), t(WF_SHADE_THREADS);
+        if (first) {
+            if (tabs)
+                hipLaunchKernelGGL((k_shade<true, true>), g, t, 0, st, a);
+            else
+                hipLaunchKernelGGL((k_shade<true, false>), g, t, 0, st, a);
+        } else {
+            if (tabs)
+                hipLaunchKernelGGL((k_shade<false, true>), g, t, 0, st, a);
+            else
+                hipLaunchKernelGGL((k_shade<false, false>), g, t, 0, st, a);
+        }
+        ++*launches;
+    };
+    auto flip = [&]() {
         std::swap(in, out);
         std::swap(shi, sho);
         std::swap(sin, sout);
@@ -656,13 +704,22 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     };
     bool flush = false;
     for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
-        one(depth, camera && depth == 0, depth > 0);
+        const bool first = camera && depth == 0;
+        trace(depth, first, depth > 0, 0);
+        if (two && depth == 0) {  // the second stream starts when the first has finished its first k_trace: one phase behind from then on
+            HIPCHK(c, hipEventRecord(c->ev_fork, strm[0]));
+            HIPCHK(c, hipStreamWaitEvent(strm[1], c->ev_fork, 0));
+        }
+        if (two) trace(depth, first, depth > 0, 1);
+        shade(depth, first, depth > 0, 0);
+        if (two) shade(depth, first, depth > 0, 1);
+        flip();
         HIPCHK(c, hipGetLastError());
-        // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces
+        // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces (one stream)
         if (a.max_depth > 32 && (depth & 7u) == 7u) {
             std::vector<uint32_t> cnt(nreg);
-            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nreg * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(c, hipStreamSynchronize(st));
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nreg * 4, hipMemcpyDeviceToHost, strm[0]));
+            HIPCHK(c, hipStreamSynchronize(strm[0]));
             uint64_t live = 0;
             for (uint32_t v : cnt) live += v;
             if (live == 0) {
@@ -673,8 +730,15 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         }
     }
     if (flush) {
-        one(a.depth, false, true);
+        const uint32_t d = a.depth;
+        trace(d, false, true, 0);
+        shade(d, false, true, 0);
+        flip();
         HIPCHK(c, hipGetLastError());
+    }
+    if (two) {  // the first stream goes on (film gather) when the second has drained
+        HIPCHK(c, hipEventRecord(c->ev_join, strm[1]));
+        HIPCHK(c, hipStreamWaitEvent(strm[0], c->ev_join, 0));
     }
     return PBRT_OK;
 }
@@ -967,7 +1031,15 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             }
             const bool walk = brute && depth >= walk_from;  // this launch walks every remaining bounce of the pass
 #ifdef PBRT_DIAG
-            if (walk) {
+            const uint32_t pair_m = (brute && depth == 0 && !walk) ? pair_merge_bounce(fuse_plan, f->max_depth) : 0u;
+            if (pair_m) {  // the whole path in one launch, two tiles per wave
+                a.merge_at = pair_m;
+                const uint32_t g2 = div_up(a.n_paths, 2u * SEG_BRUTE);
+                if (s->accel_kernel == ACCEL_K_BRUTE)
+                    hipLaunchKernelGGL(k_chain_pair<ACCEL_K_BRUTE>, dim3(g2), dim3(SEG_BRUTE), 0, st, a);
+                else
+                    hipLaunchKernelGGL(k_chain_pair<ACCEL_K_BRUTE_BIG>, dim3(g2), dim3(SEG_BRUTE), 0, st, a);
+            } else if (walk) {
                 if (depth == 0)
                     launch_walk<true>(s, a, nseg_pass, nb);
                 else

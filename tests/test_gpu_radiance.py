@@ -402,6 +402,20 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
         assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
         if k >= len(walks):
             assert st["bounce_launches"] == st["passes"] and st["bounce_model_bytes"] == 12 * st["samples"]
+    # k_chain_pair (diagnostic build, PBRT_PAIR_MERGE = merge bounce): the whole path in one launch, two 64-path tiles per wave whose
+    # survivors share the wave from the merge bounce on -- same film and counts for every merge bounce, also with a short last pass
+    if md <= 6:
+        import os
+        try:
+            for m in range(1, md):
+                os.environ["PBRT_PAIR_MERGE"] = str(m)
+                pairs = [dict(seed=5, spp=6, flags=capi.film_fuse_plan(0x3F), pass_paths=pp) for pp in (0, 4 * base.shape[0] * base.shape[1] + 7)]
+                for img, st in diag_renders(mi, capi, scene, dict(spp=6, **kw), pairs):
+                    assert np.array_equal(img, base), m
+                    assert list(st["live"]) == list(st0["live"]) and st["segments"] == st0["segments"] and st["shadow_rays"] == st0["shadow_rays"]
+                    assert st["bounce_launches"] == st["passes"]
+        finally:
+            os.environ.pop("PBRT_PAIR_MERGE", None)
     # passes: a short last pass and the fused first launch
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)
 

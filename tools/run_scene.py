@@ -9,4 +9,4 @@ for i in range(reps):
     mi.render(sc, seed=0)
     st = mi.default_context().stats()
 print(f"{os.path.basename(path)} {res}x{res}x{spp}: kernel {st['kernel_ms']:.2f} ms = {res*res*spp/st['kernel_ms']/1e3:.0f} Msamples/s, "
-      f"bounce {st['bounce_ms']:.2f} ms, segments/sample {st['segments']/st['samples']:.3f}, live {st['live'][:8]}", flush=True)
+      f"bounce {st['bounce_ms']:.2f} ms, segments/sample {st['segments']/st['samples']:.3f}, live {st['live'][:8]}, plan {st['fuse_plan']:#x}", flush=True)

@@ -420,6 +420,27 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)
 
 
+def test_bvh_passes_on_two_streams_render_the_same_film(mi):
+    """PBRT_WF_STREAMS=2 (opt-in, read once per process: a child process): the halves of a pass's regions run on two streams, one
+    phase apart -- a pass of 300 regions (two streams need >= 256) and a two-pass render give the film of the one-stream default"""
+    import hashlib, os, subprocess, sys
+    sc = mi.load_file(scene_path("testring.xml"), res=384, spp=8)
+    want = [hashlib.sha256(sc.integrator().render(sc, seed=3, spp=8, pass_paths=pp).tobytes()).hexdigest() for pp in (0, 700_000)]
+    child = ("import hashlib, sys; sys.path.insert(0, %r); import pbrt_amd as mi\n"
+             "sc = mi.load_file(%r, res=384, spp=8)\n"
+             "for pp in (0, 700_000):\n"
+             "    img = sc.integrator().render(sc, seed=3, spp=8, pass_paths=pp); st = mi.default_context().stats()\n"
+             "    print('film', hashlib.sha256(img.tobytes()).hexdigest(), st['passes'], st['bounce_launches'])\n"
+             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), scene_path("testring.xml")))
+    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, PBRT_WF_STREAMS="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("film")]
+    assert [g[1] for g in got] == want
+    md = sc.integrator().max_depth
+    assert int(got[0][2]) == 1 and int(got[0][3]) == 4 * md      # one pass: two halves x (k_trace + k_shade) per bounce
+    assert int(got[1][2]) == 2
+
+
 def test_render_larger_than_a_pass_with_an_odd_pixel_count(mi, ob, capi):
     """more samples than the 64 Mi paths of a pass, on a film whose pixel count divides nothing: 521 x 521 x 256 = 69.5 M samples run
     as two equal passes of 128 spp; a band of the film equals the oracle's render of that crop (the crop render redoes the halo rows).

@@ -159,6 +159,22 @@ def test_unbounded_depth_and_rr(mi, ob):
     assert np.array_equal(img, ref)
 
 
+@pytest.mark.parametrize("max_depth", [1, 2, 3, 40, -1])
+def test_bvh_scene_depth_budgets(mi, ob, max_depth):
+    """the k_trace / k_shade streams with the smallest depth budgets (1: emitters seen directly, 2: one next-event estimate and
+    the emitter lookup of the second bounce), with a budget above 32 (the host polls the live count every 8 bounces and stops
+    early: the shadow rays of the last shaded bounce still get their trace + shade) and unbounded (Mitsuba max_depth = -1)"""
+    sc = mi.load_file(scene_path("testring.xml"), res=48, spp=3, max_depth=max_depth)
+    img = mi.render(sc, seed=6)
+    st = mi.default_context().stats()
+    ref, _ = oracle_render(ob, sc, 6, 3)
+    assert np.array_equal(img, ref) and (img.mean() > 0 or max_depth == 1)   # (the camera does not see the emitter itself)
+    if max_depth in (40, -1):
+        assert 2 * 8 <= st["bounce_launches"] <= 2 * 33      # stopped by the poll, not by the budget
+    else:
+        assert st["bounce_launches"] == 2 * max_depth
+
+
 def test_material_update_reaches_the_device(mi, ob):
     sc = mi.load_file(scene_path("cbox.xml"), res=24, spp=4)
     a = mi.render(sc, seed=0)

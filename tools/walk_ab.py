@@ -1,10 +1,12 @@
 """A/B of the launch structure of the brute-force radiance kernels on cbox 512^2 x 256 spp: fuse plan (two bounces per launch
-in registers) x walk depth (one launch for all remaining bounces).  Film must not change.  usage: python tools/walk_ab.py"""
+in registers) x walk depth (one launch for all remaining bounces: k_walk, DIAGNOSTIC build -- the whole script runs on
+libpbrt_hip_diag.so, `make -C physics-based-ray-tracing_amd/csrc diag`).  Film must not change.  usage: python tools/walk_ab.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pbrt_amd as mi
 capi = __import__("importlib").import_module("physics-based-ray-tracing_amd._capi")
+capi.use_library(capi.DIAG_LIB_PATH).__enter__()   # for the life of the process
 sc = mi.load_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/scenes/cbox.xml"), res=512, spp=256)
 integ = sc.integrator()
 ctx = mi.default_context()

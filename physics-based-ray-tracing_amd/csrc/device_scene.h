@@ -576,6 +576,106 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
     return found;
 }
 
+// Wave-synchronous closest hit for COHERENT rays (the camera rays of an 8 x 8 pixel tile: one origin, a narrow cone of
+// directions).  The wave walks ONE path through the tree: the node index is wave-uniform (a node read is one broadcast, no bank
+// conflicts, no per-lane stack), every lane tests the node's four child boxes with its own ray and its own closest hit so far, a
+// child goes on the wave's stack if ANY lane hits it, and at a leaf every lane tests every primitive.  The stack is the 64 lanes
+// of one VGPR (written by compare + select, read by v_readlane with a scalar lane index; the host checks 3 * depth <= 64); the children are ordered by
+// the entry distances of one representative lane (`rep`, wave-uniform).
+// Same result per lane as bvh_intersect<false>: a lane sees a superset of the primitives its own traversal would have tested --
+// a primitive in a box its ray misses cannot be hit (the boxes are conservative), one behind its closest hit loses the
+// comparison -- and ties in t go to the lowest index either way.
+// `best`: in = tmax of the lane's ray (< 0: the lane has no ray), out = t of the hit.
+template <typename NodeP, typename PrimP>
+DEV bool bvh_packet_closest(NodeP nodes, PrimP lprims, const pbrt_prim *full, V3 o, V3 d, uint32_t rep, float &best, float &hu, float &hv,
+                            uint32_t &hid) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    const BoxRay r = make_box_ray(o, d);
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
+    uint32_t stk = 0;  // lane i: stack entry i
+    uint32_t sp = 0;   // wave-uniform
+    uint32_t cur = 0;  // wave-uniform child reference
+    bool found = false;
+    for (;;) {
+        if ((int32_t)cur >= 0) {
+            const auto *np = nodes + cur;
+            const u32x4 w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
+            const u32x4 w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
+            const u32x2 w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
+            const uint32_t reftab = np->child[lane & 3u];  // lane k (k < 4): reference of child k
+            const uint32_t exps = w0.w;
+            const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
+                        Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
+            const float Bx = (__uint_as_float(w0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(w0.y) - r.o.y) * r.inv.y,
+                        Bz = (__uint_as_float(w0.z) - r.o.z) * r.inv.z;
+            const uint32_t qnx = nx ? w2.w : w2.x, qfx = nx ? w2.x : w2.w;
+            const uint32_t qny = ny ? w3.x : w2.y, qfy = ny ? w2.y : w3.x;
+            const uint32_t qnz = nz ? w3.y : w2.z, qfz = nz ? w2.z : w3.y;
+            uint32_t key[4], mask = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tnx = fma_((float)((qnx >> (8 * k)) & 0xffu), Ax, Bx), tfx = fma_((float)((qfx >> (8 * k)) & 0xffu), Ax, Bx);
+                const float tny = fma_((float)((qny >> (8 * k)) & 0xffu), Ay, By), tfy = fma_((float)((qfy >> (8 * k)) & 0xffu), Ay, By);
+                const float tnz = fma_((float)((qnz >> (8 * k)) & 0xffu), Az, Bz), tfz = fma_((float)((qfz >> (8 * k)) & 0xffu), Az, Bz);
+                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
+                const bool hit = tn <= tf;
+                key[k] = ((hit ? __float_as_uint(tn) : 0xffffffffu) & ~3u) | (uint32_t)k;
+                mask |= __builtin_amdgcn_ballot_w64(hit) != 0ull ? (1u << k) : 0u;
+            }
+            uint32_t pend = BVH_SENT;
+            if (mask != 0u) {
+                // the representative lane's order, far to near: every hit child but the nearest goes on the stack
+                uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)key[0], (int)rep), s1 = (uint32_t)__builtin_amdgcn_readlane((int)key[1], (int)rep),
+                         s2 = (uint32_t)__builtin_amdgcn_readlane((int)key[2], (int)rep), s3 = (uint32_t)__builtin_amdgcn_readlane((int)key[3], (int)rep);
+                uint32_t t;
+                t = min(s0, s1), s1 = max(s0, s1), s0 = t;
+                t = min(s2, s3), s3 = max(s2, s3), s2 = t;
+                t = min(s0, s2), s2 = max(s0, s2), s0 = t;
+                t = min(s1, s3), s3 = max(s1, s3), s1 = t;
+                t = min(s1, s2), s2 = max(s1, s2), s1 = t;
+                const uint32_t order[4] = {s3, s2, s1, s0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t slot = order[i] & 3u;
+                    if ((mask >> slot) & 1u) {
+                        if (pend != BVH_SENT) {
+                            stk = lane == sp ? pend : stk;  // (v_writelane by hand: compare + select)
+                            ++sp;
+                        }
+                        pend = (uint32_t)__builtin_amdgcn_readlane((int)reftab, (int)slot);
+                    }
+                }
+            }
+            cur = pend;
+        } else {
+            const uint32_t first = cur & 0x07ffffffu, count = (cur >> 27) & 15u;
+            for (uint32_t k = 0; k < count; ++k) {
+                float t, u, v;
+                uint32_t id;
+                if (lprim_hit(lprims, first + k, full, o, d, best, &t, &u, &v, &id)) {
+                    if (!found || t < best || (t == best && id < hid)) {
+                        best = t;
+                        hu = u;
+                        hv = v;
+                        hid = id;
+                        found = true;
+                    }
+                }
+            }
+            cur = BVH_SENT;
+        }
+        if (cur == BVH_SENT) {  // nothing to descend into: the next entry of the stack
+            if (sp == 0u) break;
+            --sp;
+            cur = (uint32_t)__builtin_amdgcn_readlane((int)stk, (int)sp);
+        }
+    }
+    return found;
+}
+
 // ---- surface interaction ------------------------------------------------------------------------
 struct SI {
     V3 p, n;  // hit point, geometric normal (rays are offset along it)

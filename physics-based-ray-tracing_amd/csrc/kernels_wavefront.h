@@ -302,6 +302,63 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     }
 }
 
+// ---- k_trace_primary ---------------------------------------------------------------------------------------------------------
+// The closest hits of the CAMERA rays (bounce 0 of a render): 64 consecutive paths are the 8 x 8 pixel tile of one sample
+// (path_key), so a wave walks the tree once for all of them (device_scene.h bvh_packet_closest) instead of 64 times with 64
+// stacks.  Same grid and region walk as k_trace (workgroup w: regions w, w + G, ...); the waves of a workgroup take the 64-path
+// tiles of those regions from a counter in LDS.  Writes hit_id / hits like k_trace; same hits, bit for bit.
+// dynamic LDS: the image (ACCEL_K_BVH_LDS).
+template <int ACCEL>
+__global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(const WfArgs a) {
+    static_assert(ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS, "k_trace_primary: BVH scenes");
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
+    __shared__ uint32_t q_in;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, G = gridDim.x;
+    const uint32_t K = (a.n_regions - blockIdx.x + G - 1u) / G;  // regions of this workgroup
+    if (tid == 0) q_in = 0;
+    LdsScene ls;
+    if (ACCEL == ACCEL_K_BVH_LDS) {
+        stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
+    } else {
+        ls.nodes = a.sc.nodes;
+        ls.lprims = a.sc.lprims;
+        __syncthreads();
+    }
+    const auto nodes = ls.nodes;
+    const auto lprims = ls.lprims;
+    constexpr uint32_t TILES = WF_REGION / 64u;
+    const uint32_t n_tiles = K * TILES;
+    for (;;) {
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(&q_in, 1u);
+        const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        if (t >= n_tiles) break;
+        const uint32_t r = a.region0 + blockIdx.x + (t / TILES) * G;
+        const uint32_t slot0 = r * WF_REGION + (t % TILES) * 64u;
+        if (slot0 >= a.n_paths) continue;  // uniform: beyond the paths of this pass
+        const uint32_t slot = slot0 + lane;
+        const bool alive = slot < a.n_paths;
+        V3 o = {0, 0, 0}, d = {0, 0, 1};
+        float best = -1.0f, hu = 0.0f, hv = 0.0f;
+        uint32_t hid = 0xffffffffu;
+        if (alive) {
+            uint32_t ka, kb;
+            wf_camera_ray(a, slot, &o, &d, &best, &ka, &kb);
+        }
+        // the representative ray: the middle of the tile (lane = 8 x + y), or the first lane that has a ray
+        const unsigned long long ba = __ballot(alive);
+        const uint32_t rep = ((ba >> 27) & 1ull) ? 27u : (uint32_t)__builtin_ctzll(ba);
+        const bool found = bvh_packet_closest(nodes, lprims, a.sc.prims, o, d, rep, best, hu, hv, hid);
+        if (alive) {
+            a.hit_id[slot] = found ? hid : 0xffffffffu;
+            if (found) {
+                const float4 rec = {best, hu, hv, 0.0f};
+                a.hits[slot] = rec;
+            }
+        }
+    }
+}
+
 // ---- k_shade ---------------------------------------------------------------------------------------------------------------
 struct WfShadow {
     V3 so, sdir, A, B;

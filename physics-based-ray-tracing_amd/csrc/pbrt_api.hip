@@ -560,6 +560,7 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
 
 // ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
 struct WfPlan {
+    bool packet = true;      // camera rays: one tree walk per 64-path tile (k_trace_primary); PBRT_WF_PACKET=0: k_trace<true> (A/B)
     uint32_t streams = 1;    // PBRT_WF_STREAMS=2: the halves of a pass on two streams, one phase apart (measured +2.8 %: DESIGN.md section 7)
     uint32_t grid_deep = 2;  // workgroups per CU from bounce 2 on (few rays: a resident round of larger shares; ring 8 / 2 / 1: 139.7 / 137.1 / 134.9 ms)
     uint32_t threads = 1024, rows = 2, grid_mult = 8;  // grid: ring 1024^2 x 64: 2 / 4 / 8 / 16 workgroups per CU -> 27.6 / 21.3 / 20.4 / 21.3 ms
@@ -588,6 +589,9 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     if (e_deep) p.grid_deep = std::max(1u, (uint32_t)atoi(e_deep));
     static const char *e_str = getenv("PBRT_WF_STREAMS");
     if (e_str) p.streams = std::max(1u, (uint32_t)atoi(e_str));
+    static const char *e_pkt = getenv("PBRT_WF_PACKET");
+    if (e_pkt) p.packet = atoi(e_pkt) != 0;
+    if (3u * s->bvh_depth > 64u) p.packet = false;  // the wave's stack is the 64 lanes of one register (bvh_packet_closest)
     p.lds = (size_t)image + (size_t)p.rows * p.threads * 4u;
     return p;
 }
@@ -598,6 +602,8 @@ static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<false, ACCEL_K_BVH_LDS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_primary<ACCEL_K_BVH_LDS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
     }
     return PBRT_OK;
 }
@@ -666,7 +672,12 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         const uint32_t mult = depth >= 2 ? p.grid_deep : p.grid_mult;
         const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * (uint32_t)c->n_cu / n_half)));
         hipStream_t st = strm[h];
-        if (first) {
+        if (first && p.packet) {
+            if (lds)
+                hipLaunchKernelGGL(k_trace_primary<ACCEL_K_BVH_LDS>, dim3(G), dim3(1024), s->lds_bytes, st, a);
+            else
+                hipLaunchKernelGGL(k_trace_primary<ACCEL_K_BVH_GLOBAL>, dim3(G), dim3(1024), 0, st, a);
+        } else if (first) {
             if (lds)
                 hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
             else

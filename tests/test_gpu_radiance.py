@@ -436,25 +436,50 @@ def test_fused_bounce_launches_change_nothing(mi, ob, capi, scene, kw):
     assert np.array_equal(integ.render(sc, seed=5, spp=6, pass_paths=4 * base.shape[0] * base.shape[1] + 7, flags=capi.film_fuse_plan(0x5)), base)
 
 
+def _child_films(env, scene, res, spp, seed, pass_paths):
+    """films (sha256) and launch counts of renders in a CHILD process (the PBRT_WF_* switches are read once per process)"""
+    import os, subprocess, sys
+    child = ("import hashlib, sys; sys.path.insert(0, %r); import pbrt_amd as mi\n"
+             "sc = mi.load_file(%r, res=%d, spp=%d)\n"
+             "for pp in %r:\n"
+             "    img = sc.integrator().render(sc, seed=%d, spp=%d, pass_paths=pp); st = mi.default_context().stats()\n"
+             "    print('film', hashlib.sha256(img.tobytes()).hexdigest(), st['passes'], st['bounce_launches'])\n"
+             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), scene_path(scene), res, spp, tuple(pass_paths), seed, spp))
+    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("film")]
+
+
 def test_bvh_passes_on_two_streams_render_the_same_film(mi):
-    """PBRT_WF_STREAMS=2 (opt-in, read once per process: a child process): the halves of a pass's regions run on two streams, one
-    phase apart -- a pass of 300 regions (two streams need >= 256) and a two-pass render give the film of the one-stream default"""
-    import hashlib, os, subprocess, sys
+    """PBRT_WF_STREAMS=2 (opt-in): the halves of a pass's regions run on two streams, one phase apart -- a pass of 288 regions
+    (two streams need >= 256) and a two-pass render give the film of the one-stream default"""
+    import hashlib
     sc = mi.load_file(scene_path("testring.xml"), res=384, spp=8)
     want = [hashlib.sha256(sc.integrator().render(sc, seed=3, spp=8, pass_paths=pp).tobytes()).hexdigest() for pp in (0, 700_000)]
-    child = ("import hashlib, sys; sys.path.insert(0, %r); import pbrt_amd as mi\n"
-             "sc = mi.load_file(%r, res=384, spp=8)\n"
-             "for pp in (0, 700_000):\n"
-             "    img = sc.integrator().render(sc, seed=3, spp=8, pass_paths=pp); st = mi.default_context().stats()\n"
-             "    print('film', hashlib.sha256(img.tobytes()).hexdigest(), st['passes'], st['bounce_launches'])\n"
-             % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), scene_path("testring.xml")))
-    r = subprocess.run([sys.executable, "-c", child], env=dict(os.environ, PBRT_WF_STREAMS="2"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-2000:]
-    got = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("film")]
-    assert [g[1] for g in got] == want
+    got = _child_films(dict(PBRT_WF_STREAMS="2"), "testring.xml", 384, 8, 3, (0, 700_000))
+    assert [g[0] for g in got] == want
     md = sc.integrator().max_depth
-    assert int(got[0][2]) == 1 and int(got[0][3]) == 4 * md      # one pass: two halves x (k_trace + k_shade) per bounce
-    assert int(got[1][2]) == 2
+    assert int(got[0][1]) == 1 and int(got[0][2]) == 4 * md      # one pass: two halves x (k_trace + k_shade) per bounce
+    assert int(got[1][1]) == 2
+
+
+@pytest.mark.parametrize("scene,res,spp", [("testring.xml", 201, 5), ("bunny.xml", 97, 3)])
+def test_camera_rays_walked_per_tile_or_per_lane_give_the_same_film(mi, ob, scene, res, spp):
+    """bounce 0 of a BVH scene: k_trace_primary walks the tree once per 64-path tile (wave-uniform node, every lane tests the four
+    child boxes and every primitive of a leaf with its own ray); PBRT_WF_PACKET=0 keeps the per-lane traversal of k_trace.  Same
+    film either way (tree in LDS and in global memory; a film whose pixel count is no multiple of 64, a short last pass), and the
+    oracle's"""
+    import hashlib
+    sc = mi.load_file(scene_path(scene), res=res, spp=spp)
+    pps = (0, 2 * res * res + 17)
+    imgs = [sc.integrator().render(sc, seed=11, spp=spp, pass_paths=pp) for pp in pps]
+    want = [hashlib.sha256(i.tobytes()).hexdigest() for i in imgs]
+    assert want[0] == want[1]
+    got = _child_films(dict(PBRT_WF_PACKET="0"), scene, res, spp, 11, pps)
+    assert [g[0] for g in got] == want
+    band = (0, res // 2, res, 8)
+    ref, _ = oracle_render(ob, sc, 11, spp, crop=band)
+    assert np.array_equal(imgs[0][res // 2:res // 2 + 8], ref) and imgs[0].mean() > 0
 
 
 def test_render_larger_than_a_pass_with_an_odd_pixel_count(mi, ob, capi):

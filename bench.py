@@ -22,7 +22,7 @@ testring = config 4, cbox4k = config 5 on one GPU), 3 steps each after the headl
 against the CPU port on a bounded sample; and `seeds`: the headline render at seeds 1 and 2.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace + k_shade).  These kernels run against VALU ISSUE, not
+  roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace_primary + k_trace + k_shade).  These kernels run against VALU ISSUE, not
                   HBM, so bound = "valu": frac = valu_issue_busy x lane_active (the share of the chip's
                   f32 lane-slots that did useful work), achieved = frac x peak (78.6 T lane-ops/s = 256 CUs x 4 SIMD-32 x
                   2.4 GHz).  Both factors come from SQ counters of rocprofv3 PMC passes and are copied from
@@ -286,7 +286,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             workload = f"{cfg['scene']} ({cfg['what']}), {PPR} paths per ray; {sharding}"
         if overridden:
             workload += "  [SIZE OVERRIDDEN ON THE COMMAND LINE: not the named BASELINE workload]"
-        kernel = "k_us_bounce" if not radiance else ("k_trace + k_shade" if name == "testring" else "k_bounce")
+        kernel = "k_us_bounce" if not radiance else ("k_trace_primary + k_trace + k_shade" if name == "testring" else "k_bounce")
         frac = round(valu_busy * lane_active, 4) if (valu_busy is not None and lane_active is not None) else None
         out = {
             "metric": cfg["metric"], "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -315,7 +315,8 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                                        "only HBM traffic left is one 16-byte radiance record per path (hbm_* keys)")
         if radiance and name == "testring":
             out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
-                                       "8 waves per SIMD) and k_shade (full waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")
+                                       "8 waves per SIMD; the camera rays: k_trace_primary, one tree walk per 64-path tile) and k_shade (full "
+                                       "waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")
         if not radiance:
             out["roofline"]["note"] = ("k_us_bounce (GGX / impedance sample, expf, sinf, acosf; one launch walks every bounce of a pass)")
         if args.rehearse_on_one_gpu and world > 1:

@@ -626,7 +626,9 @@ DEV bool bvh_packet_closest(NodeP nodes, PrimP lprims, const pbrt_prim *full, V3
                 mask |= __builtin_amdgcn_ballot_w64(hit) != 0ull ? (1u << k) : 0u;
             }
             uint32_t pend = BVH_SENT;
-            if (mask != 0u) {
+            if (mask != 0u && (mask & (mask - 1u)) == 0u) {  // one child: no order to find
+                pend = (uint32_t)__builtin_amdgcn_readlane((int)reftab, (int)__builtin_ctz(mask));
+            } else if (mask != 0u) {
                 // the representative lane's order, far to near: every hit child but the nearest goes on the stack
                 uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)key[0], (int)rep), s1 = (uint32_t)__builtin_amdgcn_readlane((int)key[1], (int)rep),
                          s2 = (uint32_t)__builtin_amdgcn_readlane((int)key[2], (int)rep), s3 = (uint32_t)__builtin_amdgcn_readlane((int)key[3], (int)rep);

@@ -11,7 +11,7 @@ f = max(glob.glob(os.path.join(sys.argv[1], "raw", "**", "*kernel_trace.csv"), r
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "k_" in r["Kernel_Name"]]
 # the last pass: from the last first-bounce k_trace on
-first = max(i for i, r in enumerate(rows) if "k_trace<true" in r["Kernel_Name"] or "k_traceILb1" in r["Kernel_Name"])
+first = max(i for i, r in enumerate(rows) if "k_trace<true" in r["Kernel_Name"] or "k_trace_primary" in r["Kernel_Name"])
 while first > 0 and ("k_trace" in rows[first-1]["Kernel_Name"]) and int(rows[first]["Start_Timestamp"]) - int(rows[first-1]["Start_Timestamp"]) < 30e6: first -= 1
 rows = rows[first:]
 t0 = int(rows[0]["Start_Timestamp"])

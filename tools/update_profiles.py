@@ -22,9 +22,9 @@ if os.path.exists(b):
     shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
 kernel = "k_us_bounce" if config.startswith("us_") else "k_bounce"
 # BVH scenes: a bounce is k_trace + k_shade (kernels_wavefront.h)
-families = (kernel, kernel + "_pool") if config != "testring" else ("k_trace", "k_shade")
+families = (kernel, kernel + "_pool") if config != "testring" else ("k_trace_primary", "k_trace", "k_shade")
 if config == "testring":
-    kernel = "k_trace + k_shade"
+    kernel = "k_trace_primary + k_trace + k_shade"
 
 
 def per_dispatch(sub, ctr):

@@ -361,6 +361,25 @@ inline void to_bvh4(const HostBvh &b, HostBvh4 *out) {
         return;
     }
     bvh_detail::emit4(b, 0, 1, out);
+    // Breadth-first order: nodes [0, n) are the top of the tree for every n, so a kernel whose tree lives in global memory can keep
+    // its first nodes -- the ones every ray visits -- in LDS (kernels_wavefront.h: k_trace, ACCEL_K_BVH_GLOBAL).
+    const size_t n = out->nodes.size();
+    std::vector<uint32_t> bfs;  // bfs[new] = old
+    bfs.reserve(n);
+    bfs.push_back(0);
+    for (size_t i = 0; i < bfs.size(); ++i)
+        for (uint32_t c : out->nodes[bfs[i]].child)
+            if (!(c & 0x80000000u)) bfs.push_back(c);
+    std::vector<uint32_t> renum(n);
+    for (size_t i = 0; i < n; ++i) renum[bfs[i]] = (uint32_t)i;
+    std::vector<HostNode4> sorted(n);
+    for (size_t i = 0; i < n; ++i) {
+        HostNode4 N = out->nodes[bfs[i]];
+        for (uint32_t &c : N.child)
+            if (!(c & 0x80000000u)) c = renum[c];
+        sorted[i] = N;
+    }
+    out->nodes.swap(sorted);
 }
 
 // the leaf records in leaf order (order[slot] = caller's index)

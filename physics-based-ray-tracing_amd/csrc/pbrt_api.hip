@@ -573,7 +573,10 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     static const char *e_thr = getenv("PBRT_WF_THREADS"), *e_rows = getenv("PBRT_WF_ROWS"), *e_grid = getenv("PBRT_WF_GRID_MULT");
     const uint32_t limit = s->ctx->lds_limit ? s->ctx->lds_limit : 65536u;
     const uint32_t image = s->accel_kernel == ACCEL_K_BVH_LDS ? s->lds_bytes : 0u;
-    p.threads = image ? 1024u : 256u;
+    // 1024-thread workgroups for trees in global memory as well: what counts is the size of the queue a workgroup's waves share
+    // (bunny.ply 1024^2 x 64: 256 / 512 / 1024 threads 38.5 / 31.6 / 30.2 ms), not the LDS -- a copy of the top of the tree (the
+    // first 16 .. 1008 nodes in breadth-first order) in LDS on top of that was worth 1 - 2 %: the vector caches hold those nodes anyway
+    p.threads = 1024u;
     if (e_thr) {  // a power of two (the stack rows are addressed by a shift)
         const uint32_t want = (uint32_t)atoi(e_thr);
         p.threads = want >= 1024u ? 1024u : want >= 512u ? 512u : want >= 256u ? 256u : want >= 128u ? 128u : 64u;

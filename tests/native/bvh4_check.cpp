@@ -90,6 +90,15 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // breadth-first order (bvh_build.h to_bvh4): the inner children of node i, taken over i = 0, 1, 2, ..., are 1, 2, 3, ... -- every
+    // prefix of the array is the top of the tree
+    {
+        uint32_t next = 1;
+        for (size_t i = 0; i < b4.nodes.size(); ++i)
+            for (uint32_t cr : b4.nodes[i].child)
+                if (!(cr & 0x80000000u) && cr != next++) ++bad;
+        if (next != b4.nodes.size()) ++bad;
+    }
     // traversal check
     std::mt19937 rng(7);
     std::uniform_real_distribution<float> U(-1.f, 1.f);

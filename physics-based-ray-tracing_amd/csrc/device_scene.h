@@ -8,7 +8,9 @@
 // BVH4 inner node, 64 bytes (bvh_build.h HostNode4): lower corner of the node's box, a power-of-two grid step per axis and
 // the boxes of FOUR children on that 8-bit grid, rounded outward -- one node read decides four descents.
 // Child reference c: bit 31 set = leaf, bits 27..30 = primitive count (0..15; 0 = empty slot), bits 0..26 = first leaf record;
-// bit 31 clear = index of an inner node.  Traversal keeps a short per-lane stack of child references in LDS (BvhStack).
+// bit 31 clear = index of an inner node.  Traversal keeps a short per-lane stack of node entries in LDS (BvhStack).
+// This is the record in GLOBAL memory (one 64-byte read per node through the vector caches).  The LDS image of a small tree
+// holds the same four quads as PLANES (TreeLds below).
 struct DevNode4 {
     float org[3];
     uint32_t exps;      // biased exponents of the grid step: x | y << 8 | z << 16; bits 24..25: split axis of the collapsed BVH2 node
@@ -23,6 +25,91 @@ struct DevLeafPrim {
     float g[9];
     uint32_t meta;
 };
+// Pointers into the LDS carry their address space in the TYPE: an access through them can only be a ds_* instruction, and it
+// cannot be merged with an access to private (scratch) or global memory into one FLAT instruction through a selected pointer --
+// FLAT accesses to LDS are not ordered against the DS instructions around them (round 3: a traversal stack whose LDS rows and
+// scratch overflow had been merged that way cycled; tests/test_asm_address_spaces.py checks the compiled kernels).
+#define LDS_AS __attribute__((address_space(3)))
+#define PRIV_AS __attribute__((address_space(5)))
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+struct NodeQ {   // the four quads of a node: (org, exps) | child[4] | (qlo[3], qhi[0]) | (qhi[1], qhi[2])
+    u32x4 w0, w1, w2;
+    u32x2 w3;
+};
+struct LeafQ {   // the 40 bytes of a leaf record
+    u32x2 a, b, c, d, e;
+};
+// The tree as a kernel reads it.  TreeGlobal: nodes and leaf records through the vector caches.
+struct TreeGlobal {
+    const DevNode4 *nodes;
+    const DevLeafPrim *lprims;
+    DEV NodeQ node(uint32_t n) const {
+        const DevNode4 *np = nodes + n;
+        NodeQ q;
+        q.w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
+        q.w1 = *reinterpret_cast<const u32x4 *>(&np->child[0]);
+        q.w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
+        q.w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
+        return q;
+    }
+    DEV NodeQ node_boxes(uint32_t n) const {  // without the child references (w1 undefined)
+        const DevNode4 *np = nodes + n;
+        NodeQ q;
+        q.w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
+        q.w1 = q.w0;
+        q.w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
+        q.w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
+        return q;
+    }
+    DEV uint32_t child(uint32_t n, uint32_t slot) const { return nodes[n].child[slot]; }
+    DEV LeafQ leaf(uint32_t s) const {
+        const u32x2 *q = reinterpret_cast<const u32x2 *>(&lprims[s]);
+        return {q[0], q[1], q[2], q[3], q[4]};
+    }
+};
+// TreeLds: the image a workgroup staged into its LDS (kernels_radiance.h stage_tree_lds), n = nodes of the tree:
+//   [plane 0: (org, exps)  16 B x n][plane 1: child[4]  16 B x n][plane 2: (qlo, qhi.x)  16 B x n][plane 3: (qhi.y, qhi.z)  8 B x n]
+//   [leaf records  40 B x primitives]
+// Planes instead of the 64-byte records because of the banks: a ds_read_b128 is served in groups of 16 lanes over 64 banks, and
+// quad k of a 64-byte record n starts at bank 16 (n mod 4) + 4 k -- only FOUR bank sets for the 16 lanes of a group, whatever
+// nodes they read (35 % of the LDS cycles of round 3's k_trace were conflicts).  Quad k of node n in a plane starts at bank
+// 4 n mod 64: sixteen sets, the most a 16-byte read can have; the 4-byte read of one child reference (bvh_pop) goes from 8 to 32
+// banks.  56 instead of 64 bytes per node on top (TestRing: 65.4 -> 62.8 KB, which makes room for a fourth stack row).
+struct TreeLds {
+    const LDS_AS uint32_t *img;
+    uint32_t plane;     // bytes of a 16-byte plane: 16 n
+    uint32_t leaf_off;  // byte offset of the leaf records: 56 n
+    DEV NodeQ node(uint32_t n) const {
+        const LDS_AS char *b = reinterpret_cast<const LDS_AS char *>(img);
+        const uint32_t a = n * 16u;
+        NodeQ q;
+        q.w0 = *reinterpret_cast<const LDS_AS u32x4 *>(b + a);
+        q.w1 = *reinterpret_cast<const LDS_AS u32x4 *>(b + plane + a);
+        q.w2 = *reinterpret_cast<const LDS_AS u32x4 *>(b + 2u * plane + a);
+        q.w3 = *reinterpret_cast<const LDS_AS u32x2 *>(b + 3u * plane + n * 8u);
+        return q;
+    }
+    DEV NodeQ node_boxes(uint32_t n) const {
+        const LDS_AS char *b = reinterpret_cast<const LDS_AS char *>(img);
+        const uint32_t a = n * 16u;
+        NodeQ q;
+        q.w0 = *reinterpret_cast<const LDS_AS u32x4 *>(b + a);
+        q.w1 = q.w0;
+        q.w2 = *reinterpret_cast<const LDS_AS u32x4 *>(b + 2u * plane + a);
+        q.w3 = *reinterpret_cast<const LDS_AS u32x2 *>(b + 3u * plane + n * 8u);
+        return q;
+    }
+    DEV uint32_t child(uint32_t n, uint32_t slot) const {
+        const LDS_AS char *b = reinterpret_cast<const LDS_AS char *>(img);
+        return *reinterpret_cast<const LDS_AS uint32_t *>(b + plane + n * 16u + slot * 4u);
+    }
+    DEV LeafQ leaf(uint32_t s) const {
+        const LDS_AS u32x2 *q = reinterpret_cast<const LDS_AS u32x2 *>(reinterpret_cast<const LDS_AS char *>(img) + leaf_off + s * 40u);
+        return {q[0], q[1], q[2], q[3], q[4]};
+    }
+};
+#define LDS_IMAGE_NODE_BYTES 56u
 #define BVH_LEAF 0x80000000u
 #define BVH_SENT 0xffffffffu  // bottom of the traversal stack
 
@@ -397,38 +484,41 @@ DEV BoxRay make_box_ray(V3 o, V3 d) {
 // so the stack is never deeper than the tree (one entry per level), and taking the next child of the newest entry is register
 // arithmetic plus one 4-byte read of the node's child reference.  The newest entry lives in a register (`tos`), rows
 // 0 .. n_rows - 1 of an LDS array [row][thread] (threads a power of two: the row offset is a shift) hold the next ones,
-// anything deeper goes to a private array in scratch memory (volatile: its accesses must stay apart from the LDS ones -- merged
-// into one FLAT access through a selected pointer they would no longer be ordered against the DS instructions).  The bottom
-// of the stack is BVH_SENT: the first push stores it in row 0, the last pop brings it back.  The host checks
-// depth <= BVH_STK_MAX and nodes < 2^24.
+// anything deeper goes to a private array in scratch memory.  The two live in different address spaces BY TYPE (LDS_AS /
+// PRIV_AS): the rows can only be reached by ds_* instructions, the overflow only by scratch_* ones, and no pointer can stand
+// for both.  The bottom of the stack is BVH_SENT: the first push stores it in row 0, the last pop brings it back.  The host
+// checks depth <= BVH_STK_MAX and nodes < 2^24.
 #define BVH_STK_OVF 30
 #define BVH_STK_MAX (BVH_STK_OVF + 2)  // guaranteed capacity whatever n_rows is (>= 2 rows are always there)
 struct BvhStack {
-    uint32_t *col;     // this thread's column: entry of row r at col[r << shift]; nullptr: brute-force kernels
-    uint32_t shift;    // log2(threads of the workgroup)
-    uint32_t n_rows;   // LDS rows (>= 2)
+    LDS_AS uint32_t *col;  // this thread's column: entry of row r at col[r << shift]; nullptr: brute-force kernels
+    uint32_t shift;        // log2(threads of the workgroup)
+    uint32_t n_rows;       // LDS rows (>= 2)
 };
 struct BvhCursor {
     uint32_t cur, tos, sp;
 };
-typedef volatile uint32_t BvhOvf[BVH_STK_OVF];
+struct BvhOvf {
+    uint32_t m[BVH_STK_OVF];
+    DEV PRIV_AS uint32_t *at(uint32_t i) { return (PRIV_AS uint32_t *)(&m[0]) + min(i, (uint32_t)BVH_STK_OVF - 1u); }
+};
 DEV void bvh_push(const BvhStack &st, BvhCursor &c, BvhOvf &ovf, bool on, uint32_t entry) {
     if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // wave-uniform
     if (on) {
         if (c.sp < st.n_rows)
             st.col[c.sp << st.shift] = c.tos;
         else
-            ovf[min(c.sp - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)] = c.tos;
+            *ovf.at(c.sp - st.n_rows) = c.tos;
         c.sp += 1u;
         c.tos = entry;
     }
 }
 // the next child reference off the stack (BVH_SENT: the traversal has finished)
-template <typename NodeP>
-DEV uint32_t bvh_pop(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf) {
+template <typename Tree>
+DEV uint32_t bvh_pop(const Tree &tr, const BvhStack &st, BvhCursor &c, BvhOvf &ovf) {
     const uint32_t e = c.tos;
     if (e == BVH_SENT) return BVH_SENT;
-    const uint32_t ref = nodes[e >> 8].child[e & 3u];
+    const uint32_t ref = tr.child(e >> 8, e & 3u);
     const uint32_t n = (e >> 6) & 3u;
     if (n > 1u) {
         c.tos = (e & 0xffffff00u) | ((n - 1u) << 6) | ((e & 0x3fu) >> 2);
@@ -437,10 +527,35 @@ DEV uint32_t bvh_pop(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf)
         if (sp1 < st.n_rows)
             c.tos = st.col[sp1 << st.shift];
         else
-            c.tos = ovf[min(sp1 - st.n_rows, (uint32_t)BVH_STK_OVF - 1u)];
+            c.tos = *ovf.at(sp1 - st.n_rows);
         c.sp = sp1;
     }
     return ref;
+}
+
+// The four child boxes of a node against a ray: key[k] = entry distance of child k with the slot k in its two lowest bits
+// (tn >= 0, so the keys are ordered like the floats); a miss is 0xffffffff, or 0xfffffffc | k with MISS_SLOT (the packet walk
+// orders the children by ONE lane's keys and needs the slots of the children that lane misses).
+template <bool MISS_SLOT = false>
+DEV void bvh_child_keys(const NodeQ &q, const BoxRay &r, float best, uint32_t key[4]) {
+    const uint32_t exps = q.w0.w;
+    const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
+                Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
+    const float Bx = (__uint_as_float(q.w0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(q.w0.y) - r.o.y) * r.inv.y,
+                Bz = (__uint_as_float(q.w0.z) - r.o.z) * r.inv.z;
+    const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
+    const uint32_t qnx = nx ? q.w2.w : q.w2.x, qfx = nx ? q.w2.x : q.w2.w;   // planes the ray enters / leaves through
+    const uint32_t qny = ny ? q.w3.x : q.w2.y, qfy = ny ? q.w2.y : q.w3.x;
+    const uint32_t qnz = nz ? q.w3.y : q.w2.z, qfz = nz ? q.w2.z : q.w3.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float tnx = fma_((float)((qnx >> (8 * k)) & 0xffu), Ax, Bx), tfx = fma_((float)((qfx >> (8 * k)) & 0xffu), Ax, Bx);
+        const float tny = fma_((float)((qny >> (8 * k)) & 0xffu), Ay, By), tfy = fma_((float)((qfy >> (8 * k)) & 0xffu), Ay, By);
+        const float tnz = fma_((float)((qnz >> (8 * k)) & 0xffu), Az, Bz), tfz = fma_((float)((qfz >> (8 * k)) & 0xffu), Az, Bz);
+        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
+        key[k] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : (MISS_SLOT ? (0xfffffffcu | (uint32_t)k) : 0xffffffffu);
+    }
 }
 
 // One inner node: the four child boxes against the ray; the slots of the hit children sorted by entry distance (a
@@ -450,46 +565,24 @@ DEV void bvh_cex(uint32_t &ka, uint32_t &kb) {
     ka = lo;
     kb = hi;
 }
-template <typename NodeP>
-DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, const BoxRay &r, float best) {
-    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+template <typename Tree>
+DEV void bvh_visit(const Tree &tr, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, const BoxRay &r, float best) {
     const uint32_t node = c.cur;
-    const auto *np = nodes + node;
-    const u32x4 w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
-    const u32x4 w1 = *reinterpret_cast<const u32x4 *>(&np->child[0]);
-    const u32x4 w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
-    const u32x2 w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
-    const uint32_t exps = w0.w;
-    const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
-                Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
-    const float Bx = (__uint_as_float(w0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(w0.y) - r.o.y) * r.inv.y,
-                Bz = (__uint_as_float(w0.z) - r.o.z) * r.inv.z;
-    const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
-    const uint32_t qnx = nx ? w2.w : w2.x, qfx = nx ? w2.x : w2.w;   // planes the ray enters / leaves through
-    const uint32_t qny = ny ? w3.x : w2.y, qfy = ny ? w2.y : w3.x;
-    const uint32_t qnz = nz ? w3.y : w2.z, qfz = nz ? w2.z : w3.y;
+    const NodeQ q = tr.node(node);
     uint32_t key[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float tnx = fma_((float)((qnx >> (8 * k)) & 0xffu), Ax, Bx), tfx = fma_((float)((qfx >> (8 * k)) & 0xffu), Ax, Bx);
-        const float tny = fma_((float)((qny >> (8 * k)) & 0xffu), Ay, By), tfy = fma_((float)((qfy >> (8 * k)) & 0xffu), Ay, By);
-        const float tnz = fma_((float)((qnz >> (8 * k)) & 0xffu), Az, Bz), tfz = fma_((float)((qfz >> (8 * k)) & 0xffu), Az, Bz);
-        const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-        const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
-        key[k] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)k) : 0xffffffffu;  // tn >= 0: ordered like the floats
-    }
+    bvh_child_keys(q, r, best, key);
     bvh_cex(key[0], key[1]);
     bvh_cex(key[2], key[3]);
     bvh_cex(key[0], key[2]);
     bvh_cex(key[1], key[3]);
     bvh_cex(key[1], key[2]);
-    // (the reference of the nearest child is picked before the branch: the four references then arrive with the rest of the
-    // node instead of in a second, dependent LDS read inside it)
-    const uint32_t s0 = key[0] & 3u;
-    const uint32_t near_ref = s0 == 0u ? w1.x : (s0 == 1u ? w1.y : (s0 == 2u ? w1.z : w1.w));
+    // (the reference of the nearest child is picked before the branch, by selects: the four references arrive with the rest of
+    // the node instead of in a second, dependent LDS read)
+    const bool s_odd = (key[0] & 1u) != 0u, s_high = (key[0] & 2u) != 0u;
+    const uint32_t r_lo = s_odd ? q.w1.y : q.w1.x, r_hi = s_odd ? q.w1.w : q.w1.z;
+    const uint32_t near_ref = s_high ? r_hi : r_lo;
     if (key[0] == 0xffffffffu) {
-        c.cur = bvh_pop(nodes, st, c, ovf);
+        c.cur = bvh_pop(tr, st, c, ovf);
         return;
     }
     c.cur = near_ref;
@@ -499,27 +592,24 @@ DEV void bvh_visit(NodeP nodes, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, c
     bvh_push(st, c, ovf, n_more != 0u, entry);
 }
 
-// One leaf record against the ray (`full`: the 64-byte table, read for cones only)
-template <typename PrimP>
-DEV bool lprim_hit(PrimP lprims, uint32_t slot, const pbrt_prim *full, V3 o, V3 d, float tmax, float *t, float *u, float *v,
-                   uint32_t *id) {
-    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
-    const u32x2 *q = reinterpret_cast<const u32x2 *>(&lprims[slot]);
-    const u32x2 a = q[0], b = q[1], cc = q[2], dd = q[3], e = q[4];
-    const uint32_t meta = e.y, type = meta >> 28;
+// One leaf record against the ray (`full`: the 64-byte table, read for cones only).  CURVED = false: the scene holds triangles
+// and parallelograms only (the host knows), the sphere and cone tests are compiled out.
+template <bool CURVED = true>
+DEV bool lprim_hit(const LeafQ &L, const pbrt_prim *full, V3 o, V3 d, float tmax, float *t, float *u, float *v, uint32_t *id) {
+    const uint32_t meta = L.e.y, type = meta >> 28;
     *id = meta & 0x0fffffffu;
-    const V3 v0 = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(b.x)};
-    if (type == PBRT_PRIM_SPHERE) {
+    const V3 v0 = {__uint_as_float(L.a.x), __uint_as_float(L.a.y), __uint_as_float(L.b.x)};
+    if (CURVED && type == PBRT_PRIM_SPHERE) {
         *u = 0.0f;
         *v = 0.0f;
-        return sphere_hit(v0, __uint_as_float(b.y), o, d, tmax, t);
+        return sphere_hit(v0, __uint_as_float(L.b.y), o, d, tmax, t);
     }
-    if (type == PBRT_PRIM_CONE) {
+    if (CURVED && type == PBRT_PRIM_CONE) {
         *v = 0.0f;
         return cone_hit(full[*id], o, d, tmax, t, u);
     }
-    const V3 e1 = {__uint_as_float(b.y), __uint_as_float(cc.x), __uint_as_float(cc.y)};
-    const V3 e2 = {__uint_as_float(dd.x), __uint_as_float(dd.y), __uint_as_float(e.x)};
+    const V3 e1 = {__uint_as_float(L.b.y), __uint_as_float(L.c.x), __uint_as_float(L.c.y)};
+    const V3 e2 = {__uint_as_float(L.d.x), __uint_as_float(L.d.y), __uint_as_float(L.e.x)};
     return planar_hit(type == PBRT_PRIM_TRIANGLE, v0, e1, e2, o, d, tmax, t, u, v);
 }
 
@@ -531,8 +621,8 @@ __device__ unsigned long long g_bvh_probe[8];  // closest hit: wave trips x 64, 
 #define BVH_PROBE_FIRST_LANE() \
     (__builtin_amdgcn_mbcnt_hi((uint32_t)(__ballot(true) >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)__ballot(true), 0u)) == 0u)
 #endif
-template <bool ANY, typename NodeP, typename PrimP>
-DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const BvhStack &st, V3 o, V3 d, float tmax, Hit *h) {
+template <bool ANY, typename Tree>
+DEV bool bvh_intersect(const Tree &tr, const pbrt_prim *full, const BvhStack &st, V3 o, V3 d, float tmax, Hit *h) {
     const BoxRay br = make_box_ray(o, d);
     BvhCursor c;
     BvhOvf ovf;
@@ -547,7 +637,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
             atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 1], 1ull);
             if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 0], 64ull);
 #endif
-            bvh_visit(nodes, st, c, ovf, br, best);
+            bvh_visit(tr, st, c, ovf, br, best);
         }
         if (c.cur == BVH_SENT) break;  // this lane has finished (the wave leaves the loop when every lane has)
         const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
@@ -558,7 +648,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
             atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 3], 1ull);
             if (BVH_PROBE_FIRST_LANE()) atomicAdd(&g_bvh_probe[(ANY ? 4 : 0) + 2], 64ull);
 #endif
-            if (lprim_hit(lprims, first + k, full, o, d, best, &t, &u, &v, &id)) {
+            if (lprim_hit(tr.leaf(first + k), full, o, d, best, &t, &u, &v, &id)) {
                 if (ANY) return true;
                 if (!found || t < best || (t == best && id < h->prim)) {
                     best = t;
@@ -571,7 +661,7 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
                 }
             }
         }
-        c.cur = bvh_pop(nodes, st, c, ovf);
+        c.cur = bvh_pop(tr, st, c, ovf);
     }
     return found;
 }
@@ -586,45 +676,23 @@ DEV bool bvh_intersect(NodeP nodes, PrimP lprims, const pbrt_prim *full, const B
 // a primitive in a box its ray misses cannot be hit (the boxes are conservative), one behind its closest hit loses the
 // comparison -- and ties in t go to the lowest index either way.
 // `best`: in = tmax of the lane's ray (< 0: the lane has no ray), out = t of the hit.
-template <typename NodeP, typename PrimP>
-DEV bool bvh_packet_closest(NodeP nodes, PrimP lprims, const pbrt_prim *full, V3 o, V3 d, uint32_t rep, float &best, float &hu, float &hv,
+template <bool CURVED, typename Tree>
+DEV bool bvh_packet_closest(const Tree &tr, const pbrt_prim *full, V3 o, V3 d, uint32_t rep, float &best, float &hu, float &hv,
                             uint32_t &hid) {
-    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
-    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
     const BoxRay r = make_box_ray(o, d);
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const bool nx = r.inv.x < 0.0f, ny = r.inv.y < 0.0f, nz = r.inv.z < 0.0f;
     uint32_t stk = 0;  // lane i: stack entry i
     uint32_t sp = 0;   // wave-uniform
     uint32_t cur = 0;  // wave-uniform child reference
     bool found = false;
     for (;;) {
         if ((int32_t)cur >= 0) {
-            const auto *np = nodes + cur;
-            const u32x4 w0 = *reinterpret_cast<const u32x4 *>(&np->org[0]);
-            const u32x4 w2 = *reinterpret_cast<const u32x4 *>(&np->qlo[0]);
-            const u32x2 w3 = *reinterpret_cast<const u32x2 *>(&np->qhi[1]);
-            const uint32_t reftab = np->child[lane & 3u];  // lane k (k < 4): reference of child k
-            const uint32_t exps = w0.w;
-            const float Ax = __uint_as_float((exps & 0xffu) << 23) * r.inv.x, Ay = __uint_as_float(((exps >> 8) & 0xffu) << 23) * r.inv.y,
-                        Az = __uint_as_float(((exps >> 16) & 0xffu) << 23) * r.inv.z;
-            const float Bx = (__uint_as_float(w0.x) - r.o.x) * r.inv.x, By = (__uint_as_float(w0.y) - r.o.y) * r.inv.y,
-                        Bz = (__uint_as_float(w0.z) - r.o.z) * r.inv.z;
-            const uint32_t qnx = nx ? w2.w : w2.x, qfx = nx ? w2.x : w2.w;
-            const uint32_t qny = ny ? w3.x : w2.y, qfy = ny ? w2.y : w3.x;
-            const uint32_t qnz = nz ? w3.y : w2.z, qfz = nz ? w2.z : w3.y;
+            const NodeQ q = tr.node_boxes(cur);
+            const uint32_t reftab = tr.child(cur, lane & 3u);  // lane k (k < 4): reference of child k
             uint32_t key[4], mask = 0;
+            bvh_child_keys<true>(q, r, best, key);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float tnx = fma_((float)((qnx >> (8 * k)) & 0xffu), Ax, Bx), tfx = fma_((float)((qfx >> (8 * k)) & 0xffu), Ax, Bx);
-                const float tny = fma_((float)((qny >> (8 * k)) & 0xffu), Ay, By), tfy = fma_((float)((qfy >> (8 * k)) & 0xffu), Ay, By);
-                const float tnz = fma_((float)((qnz >> (8 * k)) & 0xffu), Az, Bz), tfz = fma_((float)((qfz >> (8 * k)) & 0xffu), Az, Bz);
-                const float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
-                const float tf = fminf(fminf(tfx, tfy), fminf(tfz, best));
-                const bool hit = tn <= tf;
-                key[k] = ((hit ? __float_as_uint(tn) : 0xffffffffu) & ~3u) | (uint32_t)k;
-                mask |= __builtin_amdgcn_ballot_w64(hit) != 0ull ? (1u << k) : 0u;
-            }
+            for (int k = 0; k < 4; ++k) mask |= __builtin_amdgcn_ballot_w64(key[k] < 0xfffffffcu) != 0ull ? (1u << k) : 0u;
             uint32_t pend = BVH_SENT;
             if (mask != 0u && (mask & (mask - 1u)) == 0u) {  // one child: no order to find
                 pend = (uint32_t)__builtin_amdgcn_readlane((int)reftab, (int)__builtin_ctz(mask));
@@ -657,7 +725,7 @@ DEV bool bvh_packet_closest(NodeP nodes, PrimP lprims, const pbrt_prim *full, V3
             for (uint32_t k = 0; k < count; ++k) {
                 float t, u, v;
                 uint32_t id;
-                if (lprim_hit(lprims, first + k, full, o, d, best, &t, &u, &v, &id)) {
+                if (lprim_hit<CURVED>(tr.leaf(first + k), full, o, d, best, &t, &u, &v, &id)) {
                     if (!found || t < best || (t == best && id < hid)) {
                         best = t;
                         hu = u;

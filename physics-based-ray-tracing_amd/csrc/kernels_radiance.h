@@ -206,24 +206,24 @@ DEV void path_key(const RadArgs &a, uint32_t home, uint32_t *ka, uint32_t *kb, u
     }
 }
 
-// LDS image of the BVH scene: [nodes | leaf records], and the workgroup's traversal stacks (device_scene.h BvhStack)
+// LDS image of the BVH scene (device_scene.h TreeLds: node planes | leaf records), and the workgroup's traversal stacks (BvhStack)
 struct LdsScene {
-    const DevNode4 *nodes;
-    const DevLeafPrim *lprims;
+    TreeLds tree;
     BvhStack stk;
 };
+#define NO_TREE_LDS TreeLds{nullptr, 0u, 0u}
 #ifndef BVH_STK_ROWS
 #define BVH_STK_ROWS 4  // LDS rows of the traversal stacks of the fused kernels; deeper entries go to scratch memory
 #endif
 #define BVH_STK_DW(threads) (BVH_STK_ROWS * (threads))
 __host__ __device__ constexpr uint32_t ilog2_c(uint32_t v) { return v <= 1u ? 0u : 1u + ilog2_c(v >> 1); }
 // threads: the workgroup size, a power of two
-#define MAKE_BVH_STACK(lds, threads) BvhStack{(lds) + threadIdx.x, ilog2_c(threads) + 0u, BVH_STK_ROWS}
+#define MAKE_BVH_STACK(lds, threads) BvhStack{(LDS_AS uint32_t *)(lds) + threadIdx.x, ilog2_c(threads) + 0u, BVH_STK_ROWS}
 // static LDS of a kernel that may walk a BVH: its traversal stacks (one dword for the brute-force variants)
 #define BVH_STACK_LDS(ACCEL, THREADS)                                                                              \
     static_assert(((THREADS) & ((THREADS)-1)) == 0, "BVH stack rows are addressed by a shift");                    \
     __shared__ uint32_t bvh_stk_lds[((ACCEL) == ACCEL_K_BVH_GLOBAL || (ACCEL) == ACCEL_K_BVH_LDS) ? BVH_STK_DW(THREADS) : 1]
-#define NO_LDS_SCENE {nullptr, nullptr, BvhStack{nullptr, 0u, 0u}}
+#define NO_LDS_SCENE {NO_TREE_LDS, BvhStack{nullptr, 0u, 0u}}
 
 // SEGMENT: the ray is a segment between two points of the scene (next-event shadow ray): brute-force
 // scenes then only walk the primitives that can occlude such a segment (DevScene::occ_prims).
@@ -234,8 +234,8 @@ DEV bool scene_intersect(const DevScene &sc, const LdsScene &ls, V3 o, V3 d, flo
 #endif
     if (ACCEL == ACCEL_K_BRUTE || ACCEL == ACCEL_K_BRUTE_BIG)
         return brute_intersect<ANY, SEGMENT, ACCEL != ACCEL_K_BRUTE>(sc, o, d, tmax, h);
-    if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(sc.nodes, sc.lprims, sc.prims, ls.stk, o, d, tmax, h);
-    return bvh_intersect<ANY>(ls.nodes, ls.lprims, sc.prims, ls.stk, o, d, tmax, h);
+    if (ACCEL == ACCEL_K_BVH_GLOBAL) return bvh_intersect<ANY>(TreeGlobal{sc.nodes, sc.lprims}, sc.prims, ls.stk, o, d, tmax, h);
+    return bvh_intersect<ANY>(ls.tree, sc.prims, ls.stk, o, d, tmax, h);
 }
 
 // ACCEL_K_BRUTE: copy the (<= 32-entry) shading tables into LDS; layout [prims | mats | emitters | light_prims | light_cdf]
@@ -275,19 +275,28 @@ DEV Tables make_tables(const DevScene &sc, const LdsScene &ls, uint32_t *tab_lds
     return global_tables(sc);  // BVH: Hit::slot is the caller's index, the hit primitive's full record comes from global memory
 }
 
-// stage nodes + leaf records into LDS (cooperative, 16 B per lane per step; both arrays are multiples of 8 bytes, the
-// image is padded to 16)
-DEV void stage_scene_lds(const DevScene &sc, uint32_t *lds, LdsScene *ls) {
-    const uint32_t node_dw = sc.n_nodes * 16, prim_dw = sc.n_prims * 10;
-    const uint4 *src_n = reinterpret_cast<const uint4 *>(sc.nodes);
-    uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (uint32_t i = threadIdx.x; i < node_dw / 4; i += blockDim.x) dst[i] = src_n[i];
-    const uint2 *src_p = reinterpret_cast<const uint2 *>(sc.lprims);
-    uint2 *dst_p = reinterpret_cast<uint2 *>(lds + node_dw);
-    for (uint32_t i = threadIdx.x; i < prim_dw / 2; i += blockDim.x) dst_p[i] = src_p[i];
-    ls->nodes = reinterpret_cast<const DevNode4 *>(lds);
-    ls->lprims = reinterpret_cast<const DevLeafPrim *>(lds + node_dw);
+// Stage the tree into LDS (cooperative): the 64-byte node records of the global image become the planes of TreeLds (quad k of
+// node n -> plane k, 16 bytes per lane per step; the fourth quad keeps its first 8 bytes), the 40-byte leaf records follow as
+// they are.  Ends with a barrier.
+DEV TreeLds stage_tree_lds(const DevScene &sc, uint32_t *lds) {
+    const uint32_t n = sc.n_nodes, plane = n * 16u, leaf_off = n * LDS_IMAGE_NODE_BYTES, prim_dw = sc.n_prims * 10u;
+    LDS_AS char *img = reinterpret_cast<LDS_AS char *>((LDS_AS uint32_t *)lds);
+    const u32x4 *src_n = reinterpret_cast<const u32x4 *>(sc.nodes);
+    for (uint32_t i = threadIdx.x; i < n * 4u; i += blockDim.x) {
+        const u32x4 q = src_n[i];
+        const uint32_t node = i >> 2, k = i & 3u;
+        if (k < 3u) {
+            *reinterpret_cast<LDS_AS u32x4 *>(img + k * plane + node * 16u) = q;
+        } else {
+            const u32x2 h = {q.x, q.y};
+            *reinterpret_cast<LDS_AS u32x2 *>(img + 3u * plane + node * 8u) = h;
+        }
+    }
+    const u32x2 *src_p = reinterpret_cast<const u32x2 *>(sc.lprims);
+    LDS_AS u32x2 *dst_p = reinterpret_cast<LDS_AS u32x2 *>(img + leaf_off);
+    for (uint32_t i = threadIdx.x; i < prim_dw / 2u; i += blockDim.x) dst_p[i] = src_p[i];
     __syncthreads();
+    return TreeLds{reinterpret_cast<const LDS_AS uint32_t *>(img), plane, leaf_off};
 }
 
 // One bounce of one path (the body shared by k_bounce and k_walk): closest hit, emission + MIS, next-event estimation with
@@ -493,8 +502,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     }
     const uint32_t live_threads = early_exit ? (min(cnt_in, SEG) + 63u) & ~63u : SEG;  // waves still present
     BVH_STACK_LDS(ACCEL, SEG);
-    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, SEG)};
-    if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
+    LdsScene ls = {NO_TREE_LDS, MAKE_BVH_STACK(bvh_stk_lds, SEG)};
+    if (ACCEL == ACCEL_K_BVH_LDS) ls.tree = stage_tree_lds(a.sc, dyn_lds);  // ends with a barrier
     if (DYN && ACCEL != ACCEL_K_BVH_LDS) __syncthreads();               // publishes the queue words
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);

@@ -103,8 +103,8 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         return;
     }
     BVH_STACK_LDS(ACCEL, SEG);
-    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, SEG)};
-    if (ACCEL == ACCEL_K_BVH_LDS) stage_scene_lds(a.sc, dyn_lds, &ls);
+    LdsScene ls = {NO_TREE_LDS, MAKE_BVH_STACK(bvh_stk_lds, SEG)};
+    if (ACCEL == ACCEL_K_BVH_LDS) ls.tree = stage_tree_lds(a.sc, dyn_lds);
     __shared__ uint32_t tab_lds[ACCEL == ACCEL_K_BRUTE ? TAB_DW : 1];
     const Tables tb = make_tables<ACCEL>(a.sc, ls, tab_lds);
     // Echo aggregation: the paths of a workgroup belong to few (angle, element) rays -- at the first bounce to ONE
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void k_us_first(const UsArgs a, uint32_t n_ray
     const V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));            // :270,273
     const V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);          // :271,273
     BVH_STACK_LDS(ACCEL, 256);
-    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, 256)};
+    LdsScene ls = {NO_TREE_LDS, MAKE_BVH_STACK(bvh_stk_lds, 256)};
     Hit h;
     const bool hit = scene_intersect<ACCEL, false>(a.sc, ls, o, d, K_INF, &h);
     if (recv == 0) {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_ray_intersect(DevScene sc, uint32_t n, 
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     BVH_STACK_LDS(ACCEL, 256);
-    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, 256)};
+    LdsScene ls = {NO_TREE_LDS, MAKE_BVH_STACK(bvh_stk_lds, 256)};
     Hit h;
     bool f = scene_intersect<ACCEL, false>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
                                            tmax[i], &h);
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_ray_test(DevScene sc, uint32_t n, const
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     BVH_STACK_LDS(ACCEL, 256);
-    LdsScene ls = {nullptr, nullptr, MAKE_BVH_STACK(bvh_stk_lds, 256)};
+    LdsScene ls = {NO_TREE_LDS, MAKE_BVH_STACK(bvh_stk_lds, 256)};
     Hit h;
     hit[i] = scene_intersect<ACCEL, true>(sc, ls, v3(o[i], o[n + i], o[2 * n + i]), v3(d[i], d[n + i], d[2 * n + i]),
                                           tmax[i], &h)

@@ -68,6 +68,7 @@ struct WfArgs {
     uint32_t index_offset, sample_index;
     uint32_t lds_bytes;          // ACCEL_K_BVH_LDS: bytes of the staged image
     uint32_t stk_rows, stk_shift;  // traversal stacks behind the image: rows, log2(threads of the workgroup)
+    uint32_t *guard;             // WF_GUARD_WORDS words of the context: [0] waves that ran into the turn guard, [1..] state of one of them
 };
 
 DEV RadArgs wf_key_args(const WfArgs &a) {  // path_key reads these members only
@@ -97,15 +98,29 @@ DEV void wf_camera_ray(const WfArgs &a, uint32_t home, V3 *o, V3 *d, float *tmax
 }
 
 // Every loop of the stream has an exit that each wave reaches; the guard below is the net under it: a wave that exceeds
-// WF_GUARD_TURNS turns leaves, records its state in g_wf_guard and the host reports PBRT_E_DEVICE instead of hanging the box.
+// WF_GUARD_TURNS turns leaves AS A WHOLE, records its state in the context's guard words (WfArgs::guard) and the host reports
+// PBRT_E_DEVICE instead of hanging the box.  `turns` counts trips of the main loop and of the node walk; both loops are
+// wave-uniform, so it lives in a scalar register and every lane of the wave sees the trip.
 #define WF_GUARD_TURNS (1u << 22)
-__device__ uint32_t g_wf_guard[32];  // [0] trips, [1..] state of the last wave that tripped
+#define WF_GUARD_WORDS 32u
+#ifndef WF_WALK_UNROLL
+#define WF_WALK_UNROLL 1     // node visits between two looks at the wave's walkers (the refill test and the guard)
+#endif
+
+template <int ACCEL>
+struct WfTree {
+    typedef TreeGlobal type;
+};
+template <>
+struct WfTree<ACCEL_K_BVH_LDS> {
+    typedef TreeLds type;
+};
 
 // ---- k_trace ---------------------------------------------------------------------------------------------------------------
 // grid: G workgroups; workgroup w walks the regions w, w + G, w + 2 G, ... (at most WF_KMAX of them) as ONE queue: for each of
 // its regions the shadow rays of the survivors, those of the ended paths, then the continuation rays.
-// dynamic LDS: [image | stack rows].
-template <bool FIRST, int ACCEL>
+// dynamic LDS: [image | stack rows].  CURVED = false: the scene holds triangles and parallelograms only.
+template <bool FIRST, int ACCEL, bool CURVED>
 __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfArgs a) {
     static_assert(ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS, "k_trace: BVH scenes");
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -132,21 +147,18 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         cum[3 * K] = run;
         q_in = 0;
     }
-    LdsScene ls;
-    uint32_t *stk_lds = dyn_lds;
-    if (ACCEL == ACCEL_K_BVH_LDS) {
-        stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
-        stk_lds = dyn_lds + (a.lds_bytes >> 2);
+    typename WfTree<ACCEL>::type tr;
+    LDS_AS uint32_t *stk_lds = (LDS_AS uint32_t *)dyn_lds;
+    if constexpr (ACCEL == ACCEL_K_BVH_LDS) {
+        tr = stage_tree_lds(a.sc, dyn_lds);  // ends with a barrier
+        stk_lds += a.lds_bytes >> 2;
     } else {
-        ls.nodes = a.sc.nodes;
-        ls.lprims = a.sc.lprims;
+        tr = TreeGlobal{a.sc.nodes, a.sc.lprims};
         __syncthreads();
     }
     const BvhStack st = {stk_lds + tid, a.stk_shift, a.stk_rows};
     const uint32_t total = cum[3 * K];
     if (total == 0) return;  // uniform
-    const auto nodes = ls.nodes;
-    const auto lprims = ls.lprims;
 
     bool busy = false, found = false;
     uint32_t rslot = 0;  // closest hit: slot of the path | shadow ray: WF_SHADOW | dest (state slot, or WF_DEAD | record)
@@ -161,50 +173,48 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     c.sp = 0;
     bool q_empty = false;   // wave-uniform
     uint32_t s_hint = 0;    // wave-uniform: segment of the wave's last fetch (queue indices only grow)
-    uint32_t turns = 0;  // wave-uniform: trips of the main loop + of the node walk
+    uint32_t turns = 0;     // wave-uniform
     for (;;) {
-        if (++turns > WF_GUARD_TURNS) {
-            const unsigned long long bb = __ballot(busy), bi = __ballot(busy && (int32_t)c.cur >= 0);
-            if (lane == 0) {
-                atomicAdd(&g_wf_guard[0], 1u);
-                g_wf_guard[1] = blockIdx.x;
-                g_wf_guard[2] = tid >> 6;
-                g_wf_guard[3] = (uint32_t)__popcll(bb);
-                g_wf_guard[4] = (uint32_t)__popcll(bi);
-                g_wf_guard[5] = 0;
-                g_wf_guard[6] = q_empty ? 1u : 0u;
-                g_wf_guard[7] = total;
-                g_wf_guard[8] = q_in;
-                g_wf_guard[9] = 0;
-                g_wf_guard[10] = a.depth | (FIRST ? 0x100u : 0u);
-                g_wf_guard[11] = K;
-            }
-            {  // the first lane that is still walking: its cursor, stack and ray
-                const unsigned long long bwk = __ballot(busy && (int32_t)c.cur >= 0);
-                if (bwk && lane == (uint32_t)__builtin_ctzll(bwk)) {
-                    g_wf_guard[12] = c.cur;
-                    g_wf_guard[13] = c.sp;
-                    g_wf_guard[14] = c.tos;
-                    g_wf_guard[15] = rslot;
-                    g_wf_guard[16] = st.col[0];
-                    g_wf_guard[17] = st.col[1u << st.shift];
-                    g_wf_guard[18] = st.col[2u << st.shift];
-                    g_wf_guard[19] = ovf[0];
-                    g_wf_guard[20] = ovf[1];
-                    g_wf_guard[21] = __float_as_uint(o.x);
-                    g_wf_guard[22] = __float_as_uint(o.y);
-                    g_wf_guard[23] = __float_as_uint(o.z);
-                    g_wf_guard[24] = __float_as_uint(d.x);
-                    g_wf_guard[25] = __float_as_uint(d.y);
-                    g_wf_guard[26] = __float_as_uint(d.z);
-                    g_wf_guard[27] = __float_as_uint(best);
-                    g_wf_guard[28] = st.n_rows;
-                    g_wf_guard[29] = st.shift;
-                    g_wf_guard[30] = a.sc.n_nodes;
-                }
+        if (turns > WF_GUARD_TURNS) {  // (uniform: the whole wave reports and leaves)
+            const unsigned long long bb = __ballot(busy), bwk = __ballot(busy && (int32_t)c.cur >= 0);
+            const uint32_t rep = bwk ? (uint32_t)__builtin_ctzll(bwk) : (uint32_t)__builtin_ctzll(__ballot(true));
+            if (lane == rep) {  // the first lane that is still walking: its cursor, stack and ray
+                uint32_t *g = a.guard;
+                atomicAdd(&g[0], 1u);
+                g[1] = blockIdx.x;
+                g[2] = tid >> 6;
+                g[3] = (uint32_t)__popcll(bb);
+                g[4] = (uint32_t)__popcll(bwk);
+                g[5] = 0;
+                g[6] = q_empty ? 1u : 0u;
+                g[7] = total;
+                g[8] = q_in;
+                g[9] = 0;
+                g[10] = a.depth | (FIRST ? 0x100u : 0u);
+                g[11] = K;
+                g[12] = c.cur;
+                g[13] = c.sp;
+                g[14] = c.tos;
+                g[15] = rslot;
+                g[16] = st.col[0];
+                g[17] = st.col[1u << st.shift];
+                g[18] = 0;
+                g[19] = *ovf.at(0);
+                g[20] = *ovf.at(1);
+                g[21] = __float_as_uint(o.x);
+                g[22] = __float_as_uint(o.y);
+                g[23] = __float_as_uint(o.z);
+                g[24] = __float_as_uint(d.x);
+                g[25] = __float_as_uint(d.y);
+                g[26] = __float_as_uint(d.z);
+                g[27] = __float_as_uint(best);
+                g[28] = st.n_rows;
+                g[29] = st.shift;
+                g[30] = a.sc.n_nodes;
             }
             break;
         }
+        ++turns;
         // ---- retire
         if (busy && c.cur == BVH_SENT) {
             if (rslot & WF_SHADOW) {
@@ -270,12 +280,17 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             continue;
         }
         // ---- one turn of the walk: inner nodes until every busy lane holds a leaf or has finished (or, while new rays can be
-        // had, until fewer than WF_WALK_MIN lanes are still walking), then the held leaves
-        const bool can_refill = !q_empty;  // wave-uniform (a prefetched record only serves its own lane, once that lane is idle)
-        while (busy && (int32_t)c.cur >= 0) {
-            if (can_refill && (uint32_t)__popcll(__ballot(true)) < WF_WALK_MIN) break;
-            if (++turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
-            bvh_visit(nodes, st, c, ovf, br, best);
+        // had, until fewer than WF_WALK_MIN lanes are still walking), then the held leaves.  The loop is wave-uniform (a scalar
+        // branch on the ballot of the walkers, looked at every WF_WALK_UNROLL visits); a lane that has left the walk idles.
+        const bool can_refill = !q_empty;  // wave-uniform
+        for (;;) {
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(busy && (int32_t)c.cur >= 0));
+            if (n_walk == 0u || (can_refill && n_walk < WF_WALK_MIN)) break;
+            turns += WF_WALK_UNROLL;
+            if (turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
+#pragma unroll
+            for (int j = 0; j < WF_WALK_UNROLL; ++j)
+                if (busy && (int32_t)c.cur >= 0) bvh_visit(tr, st, c, ovf, br, best);
         }
         if (busy && (int32_t)c.cur < 0 && c.cur != BVH_SENT) {
             const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             for (uint32_t k = 0; k < count && !stop; ++k) {
                 float t, u, v;
                 uint32_t id;
-                if (lprim_hit(lprims, first + k, a.sc.prims, o, d, best, &t, &u, &v, &id)) {
+                if (lprim_hit<CURVED>(tr.leaf(first + k), a.sc.prims, o, d, best, &t, &u, &v, &id)) {
                     if (any) {
                         found = true;
                         stop = true;
@@ -297,7 +312,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                     }
                 }
             }
-            c.cur = stop ? BVH_SENT : bvh_pop(nodes, st, c, ovf);
+            c.cur = stop ? BVH_SENT : bvh_pop(tr, st, c, ovf);
         }
     }
 }
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
 // stacks.  Same grid and region walk as k_trace (workgroup w: regions w, w + G, ...); the waves of a workgroup take the 64-path
 // tiles of those regions from a counter in LDS.  Writes hit_id / hits like k_trace; same hits, bit for bit.
 // dynamic LDS: the image (ACCEL_K_BVH_LDS).
-template <int ACCEL>
+template <int ACCEL, bool CURVED>
 __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(const WfArgs a) {
     static_assert(ACCEL == ACCEL_K_BVH_GLOBAL || ACCEL == ACCEL_K_BVH_LDS, "k_trace_primary: BVH scenes");
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -316,16 +331,13 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(c
     const uint32_t tid = threadIdx.x, lane = tid & 63u, G = gridDim.x;
     const uint32_t K = (a.n_regions - blockIdx.x + G - 1u) / G;  // regions of this workgroup
     if (tid == 0) q_in = 0;
-    LdsScene ls;
-    if (ACCEL == ACCEL_K_BVH_LDS) {
-        stage_scene_lds(a.sc, dyn_lds, &ls);  // ends with a barrier
+    typename WfTree<ACCEL>::type tr;
+    if constexpr (ACCEL == ACCEL_K_BVH_LDS) {
+        tr = stage_tree_lds(a.sc, dyn_lds);  // ends with a barrier
     } else {
-        ls.nodes = a.sc.nodes;
-        ls.lprims = a.sc.lprims;
+        tr = TreeGlobal{a.sc.nodes, a.sc.lprims};
         __syncthreads();
     }
-    const auto nodes = ls.nodes;
-    const auto lprims = ls.lprims;
     constexpr uint32_t TILES = WF_REGION / 64u;
     const uint32_t n_tiles = K * TILES;
     for (;;) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(c
         // the representative ray: the middle of the tile (lane = 8 x + y), or the first lane that has a ray
         const unsigned long long ba = __ballot(alive);
         const uint32_t rep = ((ba >> 27) & 1ull) ? 27u : (uint32_t)__builtin_ctzll(ba);
-        const bool found = bvh_packet_closest(nodes, lprims, a.sc.prims, o, d, rep, best, hu, hv, hid);
+        const bool found = bvh_packet_closest<CURVED>(tr, a.sc.prims, o, d, rep, best, hu, hv, hid);
         if (alive) {
             a.hit_id[slot] = found ? hid : 0xffffffffu;
             if (found) {

@@ -78,6 +78,7 @@ struct pbrt_scene {
     int accel_kernel = ACCEL_K_BRUTE;
     uint32_t lds_bytes = 0;
     uint32_t bvh_depth = 0;  // levels of inner nodes of the BVH4
+    bool curved = true;      // the scene holds spheres or cones (else the BVH stream kernels run without their tests)
     std::vector<void *> allocs;
     pbrt_material *d_mats = nullptr;
     uint32_t n_mats = 0;
@@ -387,7 +388,11 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
         s->ds.nodes = dn;
         s->ds.n_nodes = (uint32_t)b4.nodes.size();
         s->bvh_depth = b4.depth;
-        const size_t lds = b4.nodes.size() * sizeof(DevNode4) + (size_t)d->n_prims * sizeof(DevLeafPrim);
+        s->curved = false;
+        for (uint32_t i = 0; i < d->n_prims; ++i)
+            if (d->prims[i].type != PBRT_PRIM_TRIANGLE && d->prims[i].type != PBRT_PRIM_PARALLELOGRAM) s->curved = true;
+        // the LDS image: 56 bytes per node (planes, device_scene.h TreeLds) + the leaf records
+        const size_t lds = b4.nodes.size() * LDS_IMAGE_NODE_BYTES + (size_t)d->n_prims * sizeof(DevLeafPrim);
         // beside the image: the traversal stacks of a 1024-thread workgroup and the kernels' small static arrays (1 KiB of slack)
         if (c->lds_limit && lds + BVH_STK_DW(SEG_BVH) * 4 + 1024 <= c->lds_limit && d->accel != PBRT_ACCEL_BVH_GLOBAL) {
             s->accel_kernel = ACCEL_K_BVH_LDS;
@@ -453,7 +458,7 @@ static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t
 #endif
 // nb: bounces this launch walks (>= 2: the multi-bounce variants of the brute-force kernels, kernels_radiance.h; a.nb = nb)
 template <bool FIRST>
-static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
+static int launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
@@ -476,10 +481,11 @@ static void launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32
             hipLaunchKernelGGL((k_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
             break;
 #else
-        default:
-            break;
+        default:  // BVH scenes run k_trace / k_shade (wf_bounces); the fused BVH bounce exists in the diagnostic build only
+            return s->ctx->fail(PBRT_E_UNSUPPORTED, "launch_bounce: no fused bounce kernel for accelerator %d in this build", s->accel_kernel);
 #endif
     }
+    return PBRT_OK;
 }
 
 static int set_lds_attr(pbrt_scene *s) {
@@ -601,14 +607,26 @@ static WfPlan wf_plan(const pbrt_scene *s) {
 static int wf_set_attr(pbrt_scene *s, const WfPlan &p) {
     pbrt_ctx *c = s->ctx;
     if (s->accel_kernel == ACCEL_K_BVH_LDS) {
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<true, ACCEL_K_BVH_LDS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<false, ACCEL_K_BVH_LDS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace_primary<ACCEL_K_BVH_LDS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+#define WF_ATTR(fn, bytes) HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
+        if (s->curved) {
+            WF_ATTR((k_trace<true, ACCEL_K_BVH_LDS, true>), p.lds);
+            WF_ATTR((k_trace<false, ACCEL_K_BVH_LDS, true>), p.lds);
+            WF_ATTR((k_trace_primary<ACCEL_K_BVH_LDS, true>), s->lds_bytes);
+        } else {
+            WF_ATTR((k_trace<true, ACCEL_K_BVH_LDS, false>), p.lds);
+            WF_ATTR((k_trace<false, ACCEL_K_BVH_LDS, false>), p.lds);
+            WF_ATTR((k_trace_primary<ACCEL_K_BVH_LDS, false>), s->lds_bytes);
+        }
+#undef WF_ATTR
     }
     return PBRT_OK;
+}
+// the context's guard words (k_trace's turn guard): allocated and cleared once, cleared again after a trip
+static uint32_t *wf_guard(pbrt_ctx *c) {
+    const bool fresh = c->ws["wf_guard"].p == nullptr;
+    uint32_t *g = (uint32_t *)c->buf("wf_guard", WF_GUARD_WORDS * 4);
+    if (g && fresh && hipMemsetAsync(g, 0, WF_GUARD_WORDS * 4, c->stream) != hipSuccess) return nullptr;
+    return g;
 }
 #define WF_BYTES_PER_PATH (2 * WF_STATE_Q * 16 + 16 + 4 + 2 * 64 + 16)  // two state sets, hit, hit index, two shadow sets, Lhome
 struct WfBufs {
@@ -637,6 +655,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     a.stk_rows = p.rows;
     a.stk_shift = 0;
     while ((1u << a.stk_shift) < p.threads) ++a.stk_shift;
+    if (!(a.guard = wf_guard(c))) return PBRT_E_NOMEM;
     // the small shading tables in LDS when they fit (kernels_wavefront.h wf_tables_lds)
     const bool tabs = s->ds.n_mats <= TAB_MAX && s->ds.n_emitters <= TAB_MAX && s->ds.n_light_prims <= TAB_MAX;
     // Opt-in (PBRT_WF_STREAMS=2): the two halves of the pass's regions on two streams, the second one phase behind the first, so
@@ -675,22 +694,34 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         const uint32_t mult = depth >= 2 ? p.grid_deep : p.grid_mult;
         const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * (uint32_t)c->n_cu / n_half)));
         hipStream_t st = strm[h];
+        // template arguments: <first bounce,> tree in LDS / in global memory, scene with curved primitives
+#define WF_TRACE(F, A, C) hipLaunchKernelGGL((k_trace<F, A, C>), dim3(G), dim3(p.threads), p.lds, st, a)
+#define WF_PRIMARY(A, C) hipLaunchKernelGGL((k_trace_primary<A, C>), dim3(G), dim3(1024), lds ? s->lds_bytes : 0u, st, a)
+        const int variant = (lds ? 2 : 0) | (s->curved ? 1 : 0);
         if (first && p.packet) {
-            if (lds)
-                hipLaunchKernelGGL(k_trace_primary<ACCEL_K_BVH_LDS>, dim3(G), dim3(1024), s->lds_bytes, st, a);
-            else
-                hipLaunchKernelGGL(k_trace_primary<ACCEL_K_BVH_GLOBAL>, dim3(G), dim3(1024), 0, st, a);
+            switch (variant) {
+                case 3: WF_PRIMARY(ACCEL_K_BVH_LDS, true); break;
+                case 2: WF_PRIMARY(ACCEL_K_BVH_LDS, false); break;
+                case 1: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, true); break;
+                default: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, false); break;
+            }
         } else if (first) {
-            if (lds)
-                hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
-            else
-                hipLaunchKernelGGL((k_trace<true, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
+            switch (variant) {
+                case 3: WF_TRACE(true, ACCEL_K_BVH_LDS, true); break;
+                case 2: WF_TRACE(true, ACCEL_K_BVH_LDS, false); break;
+                case 1: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, true); break;
+                default: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, false); break;
+            }
         } else {
-            if (lds)
-                hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_LDS>), dim3(G), dim3(p.threads), p.lds, st, a);
-            else
-                hipLaunchKernelGGL((k_trace<false, ACCEL_K_BVH_GLOBAL>), dim3(G), dim3(p.threads), p.lds, st, a);
+            switch (variant) {
+                case 3: WF_TRACE(false, ACCEL_K_BVH_LDS, true); break;
+                case 2: WF_TRACE(false, ACCEL_K_BVH_LDS, false); break;
+                case 1: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, true); break;
+                default: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, false); break;
+            }
         }
+#undef WF_TRACE
+#undef WF_PRIMARY
         ++*launches;
     };
     auto shade = [&](uint32_t depth, bool first, bool have_shadows, uint32_t h) {
@@ -756,20 +787,24 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     }
     return PBRT_OK;
 }
-// after the stream has drained: did a wave of k_trace run into its turn guard?
-static int wf_check_guard(pbrt_ctx *c) {
-    uint32_t g[32];
-    HIPCHK(c, hipMemcpyFromSymbol(g, HIP_SYMBOL(g_wf_guard), sizeof g));
+// The guard words of the context come back with the statistics of a call (wf_guard_fetch queues the copy on the call's stream,
+// wf_check_guard looks at them once the stream has drained): did a wave of k_trace run into its turn guard?
+static int wf_guard_fetch(pbrt_ctx *c, uint32_t *host) {
+    uint32_t *g = wf_guard(c);
+    if (!g) return PBRT_E_NOMEM;
+    HIPCHK(c, hipMemcpyAsync(host, g, WF_GUARD_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    return PBRT_OK;
+}
+static int wf_check_guard(pbrt_ctx *c, const uint32_t *g) {
     if (g[0] == 0) return PBRT_OK;
-    const uint32_t z[32] = {0};
-    HIPCHK(c, hipMemcpyToSymbol(HIP_SYMBOL(g_wf_guard), z, sizeof z));
+    HIPCHK(c, hipMemsetAsync(wf_guard(c), 0, WF_GUARD_WORDS * 4, c->stream));
     float f[7];
     std::memcpy(f, g + 21, sizeof f);
     return c->fail(PBRT_E_DEVICE,
-                   "k_trace: %u wave(s) hit the turn guard (block %u wave %u: busy %u walking %u queue_empty %u total %u q_in %u visits %u "
-                   "depth 0x%x K %u | lane: cur %x sp %u tos %x rslot %x rows %x %x %x ovf %x %x o %g %g %g d %g %g %g best %g n_rows %u "
+                   "k_trace: %u wave(s) hit the turn guard (block %u wave %u: busy %u walking %u queue_empty %u total %u q_in %u "
+                   "depth 0x%x K %u | lane: cur %x sp %u tos %x rslot %x rows %x %x ovf %x %x o %g %g %g d %g %g %g best %g n_rows %u "
                    "shift %u nodes %u)",
-                   g[0], g[1], g[2], g[3], g[4], g[6], g[7], g[8], g[9], g[10], g[11], g[12], g[13], g[14], g[15], g[16], g[17], g[18],
+                   g[0], g[1], g[2], g[3], g[4], g[6], g[7], g[8], g[10], g[11], g[12], g[13], g[14], g[15], g[16], g[17],
                    g[19], g[20], f[0], f[1], f[2], f[3], f[4], f[5], f[6], g[28], g[29], g[30]);
 }
 
@@ -1060,11 +1095,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                     launch_walk<false>(s, a, nseg_pass, nb);
             } else
 #endif
-            if (depth == 0) {
-                launch_bounce<true>(s, a, nseg_pass, nb);
-            } else {
-                launch_bounce<false>(s, a, nseg_pass, nb);
-            }
+            if ((rc = depth == 0 ? launch_bounce<true>(s, a, nseg_pass, nb) : launch_bounce<false>(s, a, nseg_pass, nb)) != 0) return rc;
             HIPCHK(c, hipGetLastError());
             ++launches;
             if (walk) break;
@@ -1145,8 +1176,10 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                            (size_t)n_rows, dstats + HIT_ROW0);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
+    uint32_t hguard[WF_GUARD_WORDS] = {0};
+    if (wavefront && (rc = wf_guard_fetch(c, hguard)) != 0) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
-    if (wavefront && (rc = wf_check_guard(c)) != 0) return rc;
+    if (wavefront && (rc = wf_check_guard(c, hguard)) != 0) return rc;
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;
@@ -1278,8 +1311,10 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         w.sample_index = sample_index;
         uint32_t launches = 0;
         if ((rc = wf_bounces(s, w, b, p, nseg, false, &launches)) != 0) return rc;
+        uint32_t hguard[WF_GUARD_WORDS] = {0};
+        if ((rc = wf_guard_fetch(c, hguard)) != 0) return rc;
         HIPCHK(c, hipStreamSynchronize(st));
-        if ((rc = wf_check_guard(c)) != 0) return rc;
+        if ((rc = wf_check_guard(c, hguard)) != 0) return rc;
         std::vector<float> rec((size_t)n * 4);
         HIPCHK(c, hipMemcpy(rec.data(), Lh, (size_t)n * 16, hipMemcpyDeviceToHost));
         for (uint32_t i = 0; i < n; ++i)
@@ -1334,7 +1369,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
         a.out = out;
         a.seg_in = sin;
         a.seg_out = sout;
-        launch_bounce<false>(s, a, nseg);
+        if ((rc = launch_bounce<false>(s, a, nseg)) != 0) return rc;
         HIPCHK(c, hipGetLastError());
         std::swap(in, out);
         std::swap(sin, sout);

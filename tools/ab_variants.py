@@ -1,4 +1,4 @@
-"""A/B of prebuilt library variants on one box (run on the GPU box): python tools/r03_ab.py name=lib.so[,ENV=VAL,...] ...
+"""A/B of prebuilt library variants on one box (run on the GPU box): python tools/ab_variants.py name=lib.so[,ENV=VAL,...] ...
 Each variant renders the ring scene (1024^2 x 64 spp) in a child process; prints kernel ms and a hash of the film."""
 import hashlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# build library variants here (no GPU needed): tools/r03_build_ab.sh "name:-Dflags" ...   -> _ab/libpbrt_<name>.so
+# build library variants here (no GPU needed): tools/build_variants.sh "name:-Dflags" ...   -> _ab/libpbrt_<name>.so
 ROOT=$(cd "$(dirname "$0")/.." && pwd); mkdir -p $ROOT/_ab; cd $ROOT/physics-based-ray-tracing_amd/csrc
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}

@@ -1,7 +1,7 @@
 #!/bin/bash
-# GPU tests + the ring scene timing (tools/r03_check.sh [tag])
+# GPU tests + the ring scene timing (tools/gpu_check.sh [tag])
 set -o pipefail
-TAG=${1:-chk}; ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/r03_$TAG; mkdir -p $OUT
+TAG=${1:-chk}; ROOT=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$ROOT/gpurun_out/chk_$TAG; mkdir -p $OUT
 cd $ROOT
 # the first BVH radiance test alone, with a short leash (a hung kernel must not sit there for minutes)
 timeout -k 5 90 python -m pytest tests/test_gpu_configs.py -m gpu -x -q -k "ring_meshes_small" 2>&1 | tee $OUT/pytest_first.log | tail -25; rc=${PIPESTATUS[0]}; echo "first rc $rc"

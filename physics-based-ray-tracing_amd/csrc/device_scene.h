@@ -216,17 +216,17 @@ DEV bool planar_hit(bool triangle, V3 v0, V3 e1, V3 e2, V3 o, V3 d, float tmax, 
     V3 tvec = o - v0;
     V3 qvec = cross(tvec, e1);
     float us = dot(tvec, pvec), vs = dot(d, qvec), ts = dot(e2, qvec);
-    if (det < 0.0f) {
-        det = -det;
-        us = -us;
-        vs = -vs;
-        ts = -ts;
-    }
-    bool ok = det > 0.0f && us >= 0.0f && vs >= 0.0f && ts >= 0.0f;
-    if (triangle)
-        ok = ok && (us + vs <= det);
-    else
-        ok = ok && (us <= det) && (vs <= det);
+    // det < 0: all four change sign.  As a sign transfer (x ^ sign bit of det) instead of a branch; -0 becomes +0 and fails
+    // det > 0 like before, a NaN stays one.
+    const uint32_t sgn = __float_as_uint(det) & 0x80000000u;
+    det = __uint_as_float(__float_as_uint(det) ^ sgn);
+    us = __uint_as_float(__float_as_uint(us) ^ sgn);
+    vs = __uint_as_float(__float_as_uint(vs) ^ sgn);
+    ts = __uint_as_float(__float_as_uint(ts) ^ sgn);
+    // the acceptance tests without short circuits: five compares and their conjunction, no control flow (the BVH stream kernels
+    // are bound by instruction issue, and every divergent branch costs three to five scalar instructions)
+    const float lim = triangle ? us + vs : fmaxf(us, vs);  // (both <= det  <=>  the larger one is; NaNs have failed x >= 0)
+    const bool ok = (det > 0.0f) & (us >= 0.0f) & (vs >= 0.0f) & (ts >= 0.0f) & (lim <= det);
     if (!ok) return false;
     float inv = 1.0f / det;
     float tt = ts * inv;
@@ -503,7 +503,6 @@ struct BvhOvf {
     DEV PRIV_AS uint32_t *at(uint32_t i) { return (PRIV_AS uint32_t *)(&m[0]) + min(i, (uint32_t)BVH_STK_OVF - 1u); }
 };
 DEV void bvh_push(const BvhStack &st, BvhCursor &c, BvhOvf &ovf, bool on, uint32_t entry) {
-    if (__builtin_amdgcn_ballot_w64(on) == 0) return;  // wave-uniform
     if (on) {
         if (c.sp < st.n_rows)
             st.col[c.sp << st.shift] = c.tos;
@@ -568,7 +567,12 @@ DEV void bvh_cex(uint32_t &ka, uint32_t &kb) {
 template <typename Tree>
 DEV void bvh_visit(const Tree &tr, const BvhStack &st, BvhCursor &c, BvhOvf &ovf, const BoxRay &r, float best) {
     const uint32_t node = c.cur;
-    const NodeQ q = tr.node(node);
+    NodeQ q = tr.node(node);
+#ifndef PBRT_BVH_LATE_REFS
+    // (keeps the load of the child references with the other three: left alone, the compiler sinks it into the branch that uses
+    // them, a second LDS round trip per node)
+    asm volatile("" : "+v"(q.w1));
+#endif
     uint32_t key[4];
     bvh_child_keys(q, r, best, key);
     bvh_cex(key[0], key[1]);

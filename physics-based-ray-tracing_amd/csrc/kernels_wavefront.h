@@ -103,6 +103,7 @@ DEV void wf_camera_ray(const WfArgs &a, uint32_t home, V3 *o, V3 *d, float *tmax
 // wave-uniform, so it lives in a scalar register and every lane of the wave sees the trip.
 #define WF_GUARD_TURNS (1u << 22)
 #define WF_GUARD_WORDS 32u
+#define WF_IDLE 0xfffffffeu     // cursor of a lane without a ray (BVH_SENT = 0xffffffff: its ray has finished)
 #ifndef WF_WALK_UNROLL
 #define WF_WALK_UNROLL 1     // node visits between two looks at the wave's walkers (the refill test and the guard)
 #endif
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     const uint32_t total = cum[3 * K];
     if (total == 0) return;  // uniform
 
-    bool busy = false, found = false;
+    // A lane's state is its cursor: an inner node (>= 0) or a held leaf (bit 31 set) while its ray is being traced, BVH_SENT when
+    // the ray has finished and waits to be retired, WF_IDLE when the lane has no ray.  The closest hit so far is (best, hu, hv,
+    // hid); hid == 0xffffffff: none yet.
     uint32_t rslot = 0;  // closest hit: slot of the path | shadow ray: WF_SHADOW | dest (state slot, or WF_DEAD | record)
     V3 o = {0, 0, 0}, d = {0, 0, 1};
     BoxRay br = make_box_ray(o, d);
@@ -168,15 +171,15 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     uint32_t hid = 0xffffffffu;
     BvhCursor c;
     BvhOvf ovf;
-    c.cur = BVH_SENT;
+    c.cur = WF_IDLE;
     c.tos = BVH_SENT;
     c.sp = 0;
     bool q_empty = false;   // wave-uniform
     uint32_t s_hint = 0;    // wave-uniform: segment of the wave's last fetch (queue indices only grow)
-    uint32_t turns = 0;     // wave-uniform
+    uint32_t turns = 0;     // wave-uniform (kept in a scalar register by the readfirstlane at its updates)
     for (;;) {
         if (turns > WF_GUARD_TURNS) {  // (uniform: the whole wave reports and leaves)
-            const unsigned long long bb = __ballot(busy), bwk = __ballot(busy && (int32_t)c.cur >= 0);
+            const unsigned long long bb = __ballot(c.cur != WF_IDLE), bwk = __ballot((int32_t)c.cur >= 0);
             const uint32_t rep = bwk ? (uint32_t)__builtin_ctzll(bwk) : (uint32_t)__builtin_ctzll(__ballot(true));
             if (lane == rep) {  // the first lane that is still walking: its cursor, stack and ray
                 uint32_t *g = a.guard;
@@ -214,9 +217,10 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             }
             break;
         }
-        ++turns;
+        turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)(turns + 1u));
         // ---- retire
-        if (busy && c.cur == BVH_SENT) {
+        if (c.cur == BVH_SENT) {
+            const bool found = hid != 0xffffffffu;
             if (rslot & WF_SHADOW) {
                 const float vis = found ? 0.0f : 1.0f;
                 if (rslot & WF_DEAD)
@@ -224,18 +228,18 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                 else
                     reinterpret_cast<float *>(a.st_in + 4u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // q4.w of the state
             } else {
-                a.hit_id[rslot] = found ? hid : 0xffffffffu;
+                a.hit_id[rslot] = hid;
                 if (found) {
                     const float4 rec = {best, hu, hv, 0.0f};
                     a.hits[rslot] = rec;
                 }
             }
-            busy = false;
+            c.cur = WF_IDLE;
         }
         // ---- idle lanes take the next rays of the queue.  (No prefetch of the records: at 8 waves per SIMD the stream is bound
         // by VALU issue, the other waves cover the load, and the 9 registers of a record in flight would spill.)
-        const unsigned long long bw = __ballot(!busy);
-        const uint32_t nw = (uint32_t)__popcll(bw);
+        const unsigned long long bw = __builtin_amdgcn_ballot_w64(c.cur == WF_IDLE);
+        const uint32_t nw = (uint32_t)__builtin_popcountll(bw);
         if (!q_empty && (nw >= WF_REFILL_MIN || nw == 64u)) {
             uint32_t got = 0;
             if (lane == 0) got = atomicAdd(&q_in, nw);
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             if (i0 < total) {
                 while (s_hint + 1u < 3u * K && i0 >= cum[s_hint + 1u]) ++s_hint;  // uniform
             }
-            if (!busy && i < total) {
+            if (c.cur == WF_IDLE && i < total) {
                 uint32_t s = s_hint;
                 while (i >= cum[s + 1u]) ++s;
                 const uint32_t first = seg0[s];
@@ -267,53 +271,53 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                         rslot = slot;
                     }
                 }
-                busy = true;
-                found = false;
+                hid = 0xffffffffu;
                 br = make_box_ray(o, d);
                 c.cur = 0;
                 c.tos = BVH_SENT;
                 c.sp = 0;
             }
         }
-        if (__ballot(busy) == 0) {
+        if (__builtin_amdgcn_ballot_w64(c.cur != WF_IDLE) == 0ull) {
             if (q_empty) break;
             continue;
         }
-        // ---- one turn of the walk: inner nodes until every busy lane holds a leaf or has finished (or, while new rays can be
-        // had, until fewer than WF_WALK_MIN lanes are still walking), then the held leaves.  The loop is wave-uniform (a scalar
-        // branch on the ballot of the walkers, looked at every WF_WALK_UNROLL visits); a lane that has left the walk idles.
-        const bool can_refill = !q_empty;  // wave-uniform
+        // ---- one turn of the walk: inner nodes until every lane with a ray holds a leaf or has finished (or, while new rays can
+        // be had, until fewer than WF_WALK_MIN lanes are still walking), then the held leaves
+        const uint32_t walk_min = q_empty ? 1u : WF_WALK_MIN;  // wave-uniform
         for (;;) {
-            const uint32_t n_walk = (uint32_t)__popcll(__ballot(busy && (int32_t)c.cur >= 0));
-            if (n_walk == 0u || (can_refill && n_walk < WF_WALK_MIN)) break;
-            turns += WF_WALK_UNROLL;
+            const bool walking = (int32_t)c.cur >= 0;
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < walk_min) break;
+            turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)(turns + WF_WALK_UNROLL));
             if (turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
+            if (walking) bvh_visit(tr, st, c, ovf, br, best);
 #pragma unroll
-            for (int j = 0; j < WF_WALK_UNROLL; ++j)
-                if (busy && (int32_t)c.cur >= 0) bvh_visit(tr, st, c, ovf, br, best);
+            for (int j = 1; j < WF_WALK_UNROLL; ++j)
+                if ((int32_t)c.cur >= 0) bvh_visit(tr, st, c, ovf, br, best);
         }
-        if (busy && (int32_t)c.cur < 0 && c.cur != BVH_SENT) {
-            const uint32_t first = c.cur & 0x07ffffffu, count = (c.cur >> 27) & 15u;
-            const bool any = (rslot & WF_SHADOW) != 0u;
-            bool stop = false;
-            for (uint32_t k = 0; k < count && !stop; ++k) {
+        // the held leaves: a wave-uniform loop over the primitive index, every lane with a leaf of more than k primitives takes
+        // part; the closest-hit update is a select (a hit at the distance of the best one so far wins with the lower primitive
+        // index; hid = 0xffffffff loses against any).  An any-hit ray (shadow ray) ends with its first hit.
+        const bool leaf = c.cur - 0x80000000u < 0x7ffffffeu;  // bit 31 set, neither BVH_SENT nor WF_IDLE
+        const bool any = (rslot & WF_SHADOW) != 0u;
+        const uint32_t first = c.cur & 0x07ffffffu;
+        uint32_t count = leaf ? (c.cur >> 27) & 15u : 0u;
+        for (uint32_t k = 0;; ++k) {
+            const bool on = k < count;
+            if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
+            if (on) {
                 float t, u, v;
                 uint32_t id;
-                if (lprim_hit<CURVED>(tr.leaf(first + k), a.sc.prims, o, d, best, &t, &u, &v, &id)) {
-                    if (any) {
-                        found = true;
-                        stop = true;
-                    } else if (!found || t < best || (t == best && id < hid)) {
-                        best = t;
-                        hu = u;
-                        hv = v;
-                        hid = id;
-                        found = true;
-                    }
-                }
+                const bool hit = lprim_hit<CURVED>(tr.leaf(first + k), a.sc.prims, o, d, best, &t, &u, &v, &id);
+                const bool better = hit && (t < best || (t == best && id < hid) || any);
+                best = better ? t : best;
+                hu = better ? u : hu;
+                hv = better ? v : hv;
+                hid = better ? id : hid;
+                count = (hit && any) ? 0u : count;
             }
-            c.cur = stop ? BVH_SENT : bvh_pop(tr, st, c, ovf);
         }
+        if (leaf) c.cur = (any && hid != 0xffffffffu) ? BVH_SENT : bvh_pop(tr, st, c, ovf);
     }
 }
 

@@ -27,8 +27,9 @@ struct pbrt_ctx {
     int device = 0;
     int n_cu = 256;  // compute units (MI355X: 256); read from the device properties
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;          // BVH scenes: the second half of a pass's regions (wf_bounces)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t st_trace = nullptr, st_shade = nullptr;  // BVH scenes, PBRT_WF_SPLIT: streams with CU masks (wf_split_streams)
+    uint32_t split_s = 0;
+    std::vector<hipEvent_t> sync_ev;
     std::string err;
     pbrt_stats stats{};
     std::map<std::string, DevBuf> ws;  // grow-only workspace
@@ -260,15 +261,16 @@ int pbrt_ctx_destroy(pbrt_ctx *c) {
     if (!c) return PBRT_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->st_trace) (void)hipStreamSynchronize(c->st_trace);
+    if (c->st_shade) (void)hipStreamSynchronize(c->st_shade);
     for (auto &kv : c->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
-    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (auto e : c->sync_ev) (void)hipEventDestroy(e);
+    if (c->st_trace) (void)hipStreamDestroy(c->st_trace);
+    if (c->st_shade) (void)hipStreamDestroy(c->st_shade);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PBRT_OK;
@@ -567,7 +569,6 @@ static void radiance_model_bytes(const unsigned long long *live, uint32_t nd, ui
 // ---- BVH scenes: intersection and shading as separate streams (kernels_wavefront.h) -------------------------------------------
 struct WfPlan {
     bool packet = true;      // camera rays: one tree walk per 64-path tile (k_trace_primary); PBRT_WF_PACKET=0: k_trace<true> (A/B)
-    uint32_t streams = 1;    // PBRT_WF_STREAMS=2: the halves of a pass on two streams, one phase apart (measured +2.8 %: DESIGN.md section 7)
     uint32_t grid_deep = 2;  // workgroups per CU from bounce 2 on (few rays: a resident round of larger shares; ring 8 / 2 / 1: 139.7 / 137.1 / 134.9 ms)
     uint32_t threads = 1024, rows = 2, grid_mult = 8;  // grid: ring 1024^2 x 64: 2 / 4 / 8 / 16 workgroups per CU -> 27.6 / 21.3 / 20.4 / 21.3 ms
     size_t lds = 0;
@@ -596,8 +597,6 @@ static WfPlan wf_plan(const pbrt_scene *s) {
     if (e_grid) p.grid_mult = std::max(1u, (uint32_t)atoi(e_grid));
     static const char *e_deep = getenv("PBRT_WF_GRID_DEEP");
     if (e_deep) p.grid_deep = std::max(1u, (uint32_t)atoi(e_deep));
-    static const char *e_str = getenv("PBRT_WF_STREAMS");
-    if (e_str) p.streams = std::max(1u, (uint32_t)atoi(e_str));
     static const char *e_pkt = getenv("PBRT_WF_PACKET");
     if (e_pkt) p.packet = atoi(e_pkt) != 0;
     if (3u * s->bvh_depth > 64u) p.packet = false;  // the wave's stack is the 64 lanes of one register (bvh_packet_closest)
@@ -646,6 +645,44 @@ static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
     b->nshB = (uint32_t *)c->buf("wf_nshB", (size_t)nreg * 4);
     return b->stA && b->stB && b->hits && b->hit_id && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
 }
+// BVH scenes, opt-in (PBRT_WF_SPLIT=s[,parts]): the CUs are split between the two kernels of a bounce.  k_trace is bound by
+// instruction issue and k_shade by HBM, but run side by side on the same CUs they only trade wave slots (round 3: +2.8 %).  Here
+// two streams carry CU masks -- s CUs of every shader engine (32 s of the 256) run k_shade, the others k_trace -- and a pass is
+// cut into `parts` sets of regions that go through the two streams one phase apart: trace(part, d) -> shade(part, d) ->
+// trace(part, d + 1), with trace of one part running beside shade of another.  Regions share nothing (their own slots of every
+// buffer, their own statistics rows), so any order renders the same film.
+struct WfSplit {
+    uint32_t s = 0, parts = 1;  // s = 0: off
+};
+static WfSplit wf_split_env() {
+    WfSplit w;
+    static const char *e = getenv("PBRT_WF_SPLIT");
+    if (e) {
+        unsigned s_ = 0, p_ = 2;
+        if (sscanf(e, "%u%*[,:]%u", &s_, &p_) >= 1 && s_ >= 1 && s_ <= 7) {
+            w.s = s_;
+            w.parts = std::max(2u, std::min(p_, 8u));
+        }
+    }
+    return w;
+}
+static int wf_split_streams(pbrt_ctx *c, uint32_t s_cus) {
+    if (c->st_trace && c->split_s == s_cus) return PBRT_OK;
+    if (c->st_trace) {
+        (void)hipStreamDestroy(c->st_trace);
+        (void)hipStreamDestroy(c->st_shade);
+        c->st_trace = c->st_shade = nullptr;
+    }
+    // bit b of a CU mask: XCC b % 8, shader engine (b >> 3) % 4, CU b >> 5 (tools/cu_mask_probe.hip): the s highest CUs of every
+    // shader engine of every XCD shade, so both kernels have CUs on every XCD (their L2s) and every shader engine
+    uint32_t mt[8] = {0}, ms[8] = {0};
+    for (uint32_t bit = 0; bit < 256; ++bit) ((bit >> 5) >= 8u - s_cus ? ms : mt)[bit >> 5] |= 1u << (bit & 31u);
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->st_trace, 8, mt));
+    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->st_shade, 8, ms));
+    c->split_s = s_cus;
+    return PBRT_OK;
+}
+
 // The bounces of one pass.  camera: depth 0 generates its rays from the film keys (else the rays are in b.stA / b.segA).
 // Returns the number of launches through *launches.
 static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p, uint32_t nreg, bool camera, uint32_t *launches) {
@@ -658,19 +695,28 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     if (!(a.guard = wf_guard(c))) return PBRT_E_NOMEM;
     // the small shading tables in LDS when they fit (kernels_wavefront.h wf_tables_lds)
     const bool tabs = s->ds.n_mats <= TAB_MAX && s->ds.n_emitters <= TAB_MAX && s->ds.n_light_prims <= TAB_MAX;
-    // Opt-in (PBRT_WF_STREAMS=2): the two halves of the pass's regions on two streams, the second one phase behind the first, so
-    // that one half's shading (HBM-bound) runs beside the other half's tracing (VALU-bound).  Regions are independent (their own
-    // slots of every buffer, their own statistics rows), so the halves share nothing.  Measured gain 2.8 %: k_trace holds all
-    // eight wave slots of a SIMD, so a k_shade workgroup only gets onto a CU in place of a k_trace workgroup.
-    const bool two = p.streams >= 2 && nreg >= 256 && a.max_depth <= 32;
-    if (two && !c->stream2) {
-        HIPCHK(c, hipStreamCreate(&c->stream2));
-        HIPCHK(c, hipEventCreate(&c->ev_fork));
-        HIPCHK(c, hipEventCreate(&c->ev_join));
+    const WfSplit sp = wf_split_env();
+    const bool split = sp.s != 0 && c->n_cu == 256 && nreg >= 64u * sp.parts && a.max_depth <= 32;
+    const uint32_t parts = split ? sp.parts : 1u;
+    if (split) {
+        int rc = wf_split_streams(c, sp.s);
+        if (rc) return rc;
     }
-    const uint32_t n_half = two ? 2u : 1u;
-    const uint32_t reg0[2] = {0u, two ? nreg / 2u : 0u}, regn[2] = {two ? nreg / 2u : nreg, two ? nreg - nreg / 2u : 0u};
-    hipStream_t strm[2] = {c->stream, two ? c->stream2 : c->stream};
+    const uint32_t cu_trace = split ? 256u - 32u * sp.s : (uint32_t)c->n_cu;
+    hipStream_t st_t = split ? c->st_trace : c->stream, st_s = split ? c->st_shade : c->stream;
+    uint32_t reg0[8], regn[8];
+    for (uint32_t h = 0; h < parts; ++h) {
+        reg0[h] = (uint32_t)((uint64_t)nreg * h / parts);
+        regn[h] = (uint32_t)((uint64_t)nreg * (h + 1) / parts) - reg0[h];
+    }
+    // events of the split pipeline: [part][0] = its last k_trace, [part][1] = its last k_shade (a wait captures the record that
+    // precedes it, so one event per part and kind serves every depth)
+    if (split)
+        while (c->sync_ev.size() < 2u * parts + 1u) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->sync_ev.push_back(e);
+        }
     float4 *in = b.stA, *out = b.stB, *shi = b.shA, *sho = b.shB;
     uint32_t *sin = b.segA, *sout = b.segB, *ni = b.nshA, *no = b.nshB;
     auto fill = [&](uint32_t depth, bool have_shadows, uint32_t h) {
@@ -692,8 +738,8 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         fill(depth, have_shadows, h);
         const uint32_t nr = regn[h];
         const uint32_t mult = depth >= 2 ? p.grid_deep : p.grid_mult;
-        const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * (uint32_t)c->n_cu / n_half)));
-        hipStream_t st = strm[h];
+        const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * cu_trace)));
+        hipStream_t st = st_t;
         // template arguments: <first bounce,> tree in LDS / in global memory, scene with curved primitives
 #define WF_TRACE(F, A, C) hipLaunchKernelGGL((k_trace<F, A, C>), dim3(G), dim3(p.threads), p.lds, st, a)
 #define WF_PRIMARY(A, C) hipLaunchKernelGGL((k_trace_primary<A, C>), dim3(G), dim3(1024), lds ? s->lds_bytes : 0u, st, a)
@@ -726,7 +772,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     };
     auto shade = [&](uint32_t depth, bool first, bool have_shadows, uint32_t h) {
         fill(depth, have_shadows, h);
-        hipStream_t st = strm[h];
+        hipStream_t st = st_s;
         const dim3 g(regn[h]), t(WF_SHADE_THREADS);
         if (first) {
             if (tabs)
@@ -747,24 +793,32 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         std::swap(sin, sout);
         std::swap(ni, no);
     };
+    if (split) {  // both masked streams start behind whatever the context's stream holds
+        hipEvent_t e0 = c->sync_ev[2u * parts];
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(st_t, e0, 0));
+        HIPCHK(c, hipStreamWaitEvent(st_s, e0, 0));
+    }
     bool flush = false;
     for (uint32_t depth = 0; depth < a.max_depth; ++depth) {
         const bool first = camera && depth == 0;
-        trace(depth, first, depth > 0, 0);
-        if (two && depth == 0) {  // the second stream starts when the first has finished its first k_trace: one phase behind from then on
-            HIPCHK(c, hipEventRecord(c->ev_fork, strm[0]));
-            HIPCHK(c, hipStreamWaitEvent(strm[1], c->ev_fork, 0));
+        for (uint32_t h = 0; h < parts; ++h) {
+            if (split && depth > 0) HIPCHK(c, hipStreamWaitEvent(st_t, c->sync_ev[2u * h + 1u], 0));  // shade(h, depth - 1)
+            trace(depth, first, depth > 0, h);
+            if (split) HIPCHK(c, hipEventRecord(c->sync_ev[2u * h], st_t));
         }
-        if (two) trace(depth, first, depth > 0, 1);
-        shade(depth, first, depth > 0, 0);
-        if (two) shade(depth, first, depth > 0, 1);
+        for (uint32_t h = 0; h < parts; ++h) {
+            if (split) HIPCHK(c, hipStreamWaitEvent(st_s, c->sync_ev[2u * h], 0));  // trace(h, depth)
+            shade(depth, first, depth > 0, h);
+            if (split) HIPCHK(c, hipEventRecord(c->sync_ev[2u * h + 1u], st_s));
+        }
         flip();
         HIPCHK(c, hipGetLastError());
-        // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces (one stream)
+        // unbounded depth (Mitsuba max_depth = -1): poll the live count every 8 bounces (never split: one stream)
         if (a.max_depth > 32 && (depth & 7u) == 7u) {
             std::vector<uint32_t> cnt(nreg);
-            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nreg * 4, hipMemcpyDeviceToHost, strm[0]));
-            HIPCHK(c, hipStreamSynchronize(strm[0]));
+            HIPCHK(c, hipMemcpyAsync(cnt.data(), sin, (size_t)nreg * 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
             uint64_t live = 0;
             for (uint32_t v : cnt) live += v;
             if (live == 0) {
@@ -781,10 +835,8 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         flip();
         HIPCHK(c, hipGetLastError());
     }
-    if (two) {  // the first stream goes on (film gather) when the second has drained
-        HIPCHK(c, hipEventRecord(c->ev_join, strm[1]));
-        HIPCHK(c, hipStreamWaitEvent(strm[0], c->ev_join, 0));
-    }
+    if (split)  // the context's stream goes on (film gather) when every part has been shaded
+        for (uint32_t h = 0; h < parts; ++h) HIPCHK(c, hipStreamWaitEvent(c->stream, c->sync_ev[2u * h + 1u], 0));
     return PBRT_OK;
 }
 // The guard words of the context come back with the statistics of a call (wf_guard_fetch queues the copy on the call's stream,

@@ -22,15 +22,16 @@ testring = config 4, cbox4k = config 5 on one GPU), 3 steps each after the headl
 against the CPU port on a bounded sample; and `seeds`: the headline render at seeds 1 and 2.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace_primary + k_trace + k_shade).  These kernels run against VALU ISSUE, not
-                  HBM, so bound = "valu": frac = valu_issue_busy x lane_active (the share of the chip's
-                  f32 lane-slots that did useful work), achieved = frac x peak (78.6 T lane-ops/s = 256 CUs x 4 SIMD-32 x
-                  2.4 GHz).  Both factors come from SQ counters of rocprofv3 PMC passes and are copied from
+  roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace_primary + k_trace + k_shade), bound = "hbm" as the contract
+                  defines it: achieved = ALGORITHMIC bytes of the launches (DESIGN.md byte model, evaluated on the live-path
+                  counters of this very run) / their HIP-event durations on the library's stream, frac = achieved / 8 TB/s --
+                  measured by every run.  `traffic` = HBM bytes per launch from rocprofv3 PMC passes, copied from
                   profiles/pmc_traffic.json only if that file was recorded for the kernel sources this run uses (sha256 of
-                  csrc/), else frac / achieved are null.  The HBM side rides along as hbm_* keys: hbm_achieved = ALGORITHMIC
-                  bytes of the launches (DESIGN.md byte model, evaluated on the live-path counters of this very run) / their
-                  HIP-event durations on the library's stream, against 8 TB/s; `traffic` = HBM bytes per launch from the PMC
-                  passes (same file, same hash guard), `traffic_source` says which.
+                  csrc/), else null; `traffic_source` says which, `traffic_over_algorithmic` is their ratio.  These kernels run
+                  against VALU ISSUE, not HBM; that side rides along as valu_* keys (valu_frac =
+                  valu_issue_busy x lane_active, the share of the chip's 78.6 T f32 lane-slots per second that did work; same
+                  file, same hash guard, null when not recorded).
+  per_rank_ms  -- N > 1: every rank's render / acquisition time per step and (collective_ms) its time in the gather / reduce.
   cpu_baseline -- the CPU oracle (C++ port of the same algorithm, same RNG: the reference's Python / Mitsuba path
                   cannot run on this box) on the host cores, on a bounded sample of the same workload (~15 s), rank 0,
                   N = 1 only; the same run gives the per-pixel L2 between the HIP result and the CPU result.
@@ -95,6 +96,13 @@ def launch_ranks(args, argv):
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ):
         print("bench.py: --gpus N > 1 would launch ranks from a profiled process; run one rank per rocprofv3 instead", file=sys.stderr)
         return 2
+    if not args.rehearse_on_one_gpu:
+        import torch  # (device_count() does not initialise the GPU; the ranks are fresh child processes either way)
+        have = torch.cuda.device_count()
+        if args.gpus > have:
+            print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); a multi-rank rehearsal on one GPU is "
+                  f"--rehearse-on-one-gpu (gloo, not a benchmark)", file=sys.stderr)
+            return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -228,33 +236,65 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         torch.cuda.synchronize()
 
     keep = {}
+    # this rank's own clock, split at the collective: the render / acquisition (library calls, synchronous on return) and the
+    # gather / reduce (which includes the wait for the slowest rank) -- rank 0's line lists every rank's pair (per_rank_ms,
+    # collective_ms), so a band imbalance or a slow link shows in the record of the run itself
+    mine = dict(work=0.0, coll=0.0)
 
     def step():
+        t_a = time.perf_counter()
         if radiance:
             tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
                                             tile=keep.get("tile"))
             keep["tile"] = tile
             if args.rehearse_on_one_gpu and world > 1:
                 tile = tile.cpu()  # gloo gathers host tensors
-            return par.gather_film(tile, layout, RES, RES, rank, world, force_collective=env["force"])
+            torch.cuda.synchronize()
+            t_b = time.perf_counter()
+            if "parts" not in keep:  # the gather list of rank 0, allocated once, outside the timed steps
+                keep["parts"] = par.gather_buffers(tile, rank, world, force_collective=env["force"])
+            film = par.gather_film(tile, layout, RES, RES, rank, world, force_collective=env["force"], parts=keep["parts"])
+            if tile.is_cuda:
+                torch.cuda.synchronize()
+            mine["work"] += t_b - t_a
+            mine["coll"] += time.perf_counter() - t_b
+            return film
+        tm = {}
         buf = par.distributed_acquire(scene, PPR, seed=seed, device=device, on_call=account,
-                                      host_collective=bool(args.rehearse_on_one_gpu and world > 1), force_collective=env["force"])
+                                      host_collective=bool(args.rehearse_on_one_gpu and world > 1), force_collective=env["force"],
+                                      timing=tm)
+        mine["work"] += tm.get("work_s", time.perf_counter() - t_a)
+        mine["coll"] += tm.get("collective_s", 0.0)
         return buf
 
     for _ in range(warmup):
         step()
+    if warmup == 0 and radiance and (world > 1 or env["force"]):  # no warm-up step to allocate the gather list in
+        tile0, _ = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, render_band=lambda crop, view: None)
+        keep["tile"] = tile0
+        keep["parts"] = par.gather_buffers(tile0.cpu() if (args.rehearse_on_one_gpu and world > 1) else tile0, rank, world,
+                                           force_collective=env["force"])
     for k in acc:
         acc[k] = 0
+    mine["work"] = mine["coll"] = 0.0
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         result = step()
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else device)
+        cdev = "cpu" if args.rehearse_on_one_gpu else device
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        pr = torch.tensor([mine["work"], mine["coll"]], dtype=torch.float64, device=cdev)
+        allpr = [torch.zeros_like(pr) for _ in range(world)]
+        dist.all_gather(allpr, pr)
+        per_rank = [[float(x[0]) / steps * 1e3, float(x[1]) / steps * 1e3] for x in allpr]
+    elif env["force"]:
+        per_rank = [[mine["work"] / steps * 1e3, mine["coll"] / steps * 1e3]]
 
     out = None
     if rank == 0:
@@ -273,6 +313,9 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                     valu_busy = rec.get("valu_issue_busy")
                     lane_active = rec.get("lane_active")
                     traffic_source = f"profiles/pmc_traffic.json[{name}] recorded on these kernel sources ({src_hash}): {rec.get('how', '')}"
+                    cal = rec.get("calibration_file")
+                    if cal and not os.path.exists(os.path.join(ROOT, cal)):
+                        traffic_source += f"  [calibration file {cal} is missing]"
                 elif rec:
                     traffic_source += f"; profiles/pmc_traffic.json[{name}] is for sources {rec.get('kernel_source_sha16')}, this run uses {src_hash}"
             except Exception:
@@ -287,28 +330,36 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         if overridden:
             workload += "  [SIZE OVERRIDDEN ON THE COMMAND LINE: not the named BASELINE workload]"
         kernel = "k_us_bounce" if not radiance else ("k_trace_primary + k_trace + k_shade" if name == "testring" else "k_bounce")
-        frac = round(valu_busy * lane_active, 4) if (valu_busy is not None and lane_active is not None) else None
+        valu_frac = round(valu_busy * lane_active, 4) if (valu_busy is not None and lane_active is not None) else None
+        alg_per_launch = acc["bounce_bytes"] / max(acc["launches"], 1)
         out = {
             "metric": cfg["metric"], "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak" if (world == 1 and name == "cbox") else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "baseline_config": cfg["baseline_config"], "samples_per_step": total_units, "seed": seed,
                        "mean_segments_per_sample": round(acc["segments"] / max(acc["samples"], 1), 4)},
-            # the roof these kernels run against is VALU issue, dead lanes taken out
-            "roofline": {"bound": "valu", "kernel": kernel,
-                         "achieved": round(frac * VALU_PEAK_TLANEOPS, 2) if frac is not None else None,
-                         "peak": round(VALU_PEAK_TLANEOPS, 2), "unit": "T f32 lane-op/s", "frac": frac,
-                         "valu_issue_busy": valu_busy, "lane_active": lane_active,
+            # The contract's roofline: ALGORITHMIC bytes of the bounce launches (DESIGN.md byte model, evaluated on the live-path
+            # counters of this very run) / their HIP-event durations on the library's stream, against the 8 TB/s of HBM3E --
+            # measured by every run, always numeric.  What these kernels actually run against is VALU issue (DESIGN.md section
+            # 7); those figures come from PMC passes and ride along as valu_* keys when they were recorded for these sources.
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if (traffic and alg_per_launch) else None,
+                         "algorithmic_bytes_per_launch": round(alg_per_launch),
+                         "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 5), "launches": acc["launches"],
+                         "kernel_ms_per_step": round(acc["kernel_ms"] / steps, 3), "scope": "rank 0's launches of the timed steps",
+                         "valu_frac": valu_frac, "valu_issue_busy": valu_busy, "lane_active": lane_active,
+                         "valu_peak": round(VALU_PEAK_TLANEOPS, 2), "valu_unit": "T f32 lane-op/s",
+                         "valu_achieved": round(valu_frac * VALU_PEAK_TLANEOPS, 2) if valu_frac is not None else None,
                          "valu_source": ("SQ_INSTS_VALU / (16 x SQ_BUSY_CYCLES) and SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU) of the "
                                          "dominant kernels, 4th pass of tools/profile_bench.sh (a wave64 VALU instruction occupies its SIMD-32 "
                                          "for 2 cycles; 1024 SIMDs, the counters are summed over 32 shader engines)"
-                                         if valu_busy is not None else "not recorded for these kernel sources"),
-                         "hbm_achieved": round(achieved, 2), "hbm_peak": HBM_PEAK_GBS, "hbm_unit": "GB/s",
-                         "hbm_frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": round(acc["bounce_bytes"] / max(acc["launches"], 1)),
-                         "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 5), "launches": acc["launches"],
-                         "kernel_ms_per_step": round(acc["kernel_ms"] / steps, 3), "scope": "rank 0's launches of the timed steps"},
+                                         if valu_busy is not None else "not recorded for these kernel sources")},
         }
+        if per_rank is not None:
+            out["per_rank_ms"] = [round(x[0], 3) for x in per_rank]     # render / acquisition per step, rank by rank
+            out["collective_ms"] = [round(x[1], 3) for x in per_rank]   # gather / reduce per step incl. the wait for the slowest rank
+            out["gather_ms"] = round(per_rank[0][1], 3)                  # rank 0's: it ends when the last band has arrived
         if radiance and name in ("cbox", "cbox4k"):
             out["roofline"]["note"] = ("the brute-force bounce kernels walk up to six bounces of a path in registers (the library picks the chain "
                                        "lengths from the path survival of the scene's last render; Cornell box: one launch per pass), so the "

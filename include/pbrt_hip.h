@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PBRT_ABI_VERSION 3
+#define PBRT_ABI_VERSION 4
 
 /* ---- error classes ------------------------------------------------------------------------ */
 #define PBRT_OK 0
@@ -295,6 +295,17 @@ int pbrt_ctx_create(int device, pbrt_ctx **out);
 int pbrt_ctx_destroy(pbrt_ctx *ctx);
 const char *pbrt_last_error(pbrt_ctx *ctx); /* ctx may be NULL: last ctx-less error */
 int pbrt_get_stats(pbrt_ctx *ctx, pbrt_stats *out);
+/* Workspace policy (ABI 4).  A context keeps the device buffers of its calls (path state, ray and radiance records, film
+ * accumulators) and re-uses them; pbrt_stats.workspace_bytes says how much it holds.  BVH scenes size a pass to the largest power
+ * of two of paths (1 .. 256 Mi, 356 B each) that fits 40 % of the free device memory -- up to 95.6 GB on an idle MI355X.  A caller
+ * that shares the device (the reference's driver imports torch beside the renderer, USMain.py:5) bounds that with a limit -- here,
+ * or PBRT_WORKSPACE_LIMIT_BYTES in the environment at pbrt_ctx_create; 0 = none -- and hands memory back with pbrt_ctx_trim.
+ * Under a limit, and when an allocation fails, renders take smaller passes (same film, more passes); a request that cannot be met
+ * at the smallest pass returns PBRT_E_NOMEM.  pbrt_film_desc.pass_paths still overrides the choice per call. */
+int pbrt_ctx_set_workspace_limit(pbrt_ctx *ctx, uint64_t bytes);
+/* frees every workspace buffer the most recent call did not use and every one larger than that call needed; *held_after
+ * (may be NULL) = bytes still held */
+int pbrt_ctx_trim(pbrt_ctx *ctx, uint64_t *held_after);
 
 /* replaces: mi.load_dict / mi.load_file scene instantiation + accel build (USMain.py:257) */
 int pbrt_scene_create(pbrt_ctx *ctx, const pbrt_scene_desc *desc, pbrt_scene **out);

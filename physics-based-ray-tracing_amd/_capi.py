@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbrt_hip.so")  # override: A/B builds
 
-PBRT_ABI_VERSION = 3
+PBRT_ABI_VERSION = 4
 
 # primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
@@ -155,6 +155,8 @@ SIGNATURES = {
     "pbrt_ctx_destroy": (C.c_int, [_P]),
     "pbrt_last_error": (C.c_char_p, [_P]),
     "pbrt_get_stats": (C.c_int, [_P, C.POINTER(Stats)]),
+    "pbrt_ctx_set_workspace_limit": (C.c_int, [_P, C.c_uint64]),
+    "pbrt_ctx_trim": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "pbrt_scene_create": (C.c_int, [_P, C.POINTER(SceneDesc), C.POINTER(_P)]),
     "pbrt_scene_update_material": (C.c_int, [_P, C.c_uint32, C.POINTER(Material)]),
     "pbrt_scene_destroy": (C.c_int, [_P]),
@@ -300,6 +302,16 @@ class Context:
         st = Stats()
         self.check(self.lib.pbrt_get_stats(self.handle, C.byref(st)), "pbrt_get_stats")
         return st.as_dict()
+
+    def set_workspace_limit(self, n_bytes: int) -> None:
+        """cap the device memory this context keeps for its calls (0: none); renders then take smaller passes"""
+        self.check(self.lib.pbrt_ctx_set_workspace_limit(self.handle, C.c_uint64(int(n_bytes))), "pbrt_ctx_set_workspace_limit")
+
+    def trim(self) -> int:
+        """hand back what the last call did not need; -> bytes still held"""
+        held = C.c_uint64(0)
+        self.check(self.lib.pbrt_ctx_trim(self.handle, C.byref(held)), "pbrt_ctx_trim")
+        return int(held.value)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -20,7 +20,9 @@ static std::string g_ctxless_error;
 
 struct DevBuf {
     void *p = nullptr;
-    size_t bytes = 0;
+    size_t bytes = 0;   // allocated
+    size_t need = 0;    // what the most recent request asked for
+    uint64_t stamp = 0; // pbrt_ctx::call_seq of that request
 };
 
 struct pbrt_ctx {
@@ -32,7 +34,24 @@ struct pbrt_ctx {
     std::vector<hipEvent_t> sync_ev;
     std::string err;
     pbrt_stats stats{};
-    std::map<std::string, DevBuf> ws;  // grow-only workspace
+    // Workspace: named device buffers that grow on demand and are re-used by later calls.  ws_limit (0: none) caps their sum --
+    // PBRT_WORKSPACE_LIMIT_BYTES at pbrt_ctx_create, pbrt_ctx_set_workspace_limit later; a request that would exceed it fails with
+    // PBRT_E_NOMEM and the render paths answer by taking smaller passes -- and pbrt_ctx_trim gives back what the last call did
+    // not need (a caller that shares the device with another allocator, e.g. torch beside the renderer as in USMain.py:5).
+    std::map<std::string, DevBuf> ws;
+    size_t ws_limit = 0;
+    uint64_t call_seq = 0;  // bumped by every entry point that takes workspace
+    size_t ws_total() const {
+        size_t t = 0;
+        for (const auto &kv : ws) t += kv.second.bytes;
+        return t;
+    }
+    void release(const char *name) {
+        auto it = ws.find(name);
+        if (it == ws.end()) return;
+        if (it->second.p) (void)hipFree(it->second.p);
+        ws.erase(it);
+    }
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t lds_limit = 0;
@@ -49,13 +68,22 @@ struct pbrt_ctx {
     // returns nullptr on failure (err set)
     void *buf(const char *name, size_t bytes) {
         DevBuf &b = ws[name];
+        b.need = bytes;
+        b.stamp = call_seq;
         if (b.bytes >= bytes && b.p) return b.p;
         if (b.p) (void)hipFree(b.p);
         b.p = nullptr;
         b.bytes = 0;
-        size_t want = bytes + bytes / 8 + 256;
+        // small buffers get 12.5 % of slack (a slightly larger request re-uses them); the large ones -- path state, ray and
+        // radiance records, sized by the pass -- are allocated as asked
+        const size_t want = bytes < (size_t(64) << 20) ? bytes + bytes / 8 + 256 : bytes + 256;
+        if (ws_limit && ws_total() + want > ws_limit) {
+            fail(PBRT_E_NOMEM, "workspace limit: %s wants %zu bytes on top of %zu held, limit %zu", name, want, ws_total(), ws_limit);
+            return nullptr;
+        }
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) {
+            (void)hipGetLastError();
             fail(PBRT_E_NOMEM, "hipMalloc(%zu) for %s: %s", want, name, hipGetErrorString(e));
             b.p = nullptr;
             return nullptr;
@@ -248,6 +276,7 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
         delete c;
         return PBRT_E_DEVICE;
     }
+    if (const char *lim = getenv("PBRT_WORKSPACE_LIMIT_BYTES")) c->ws_limit = (size_t)strtoull(lim, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         c->lds_limit = (uint32_t)prop.sharedMemPerBlock;
@@ -277,6 +306,32 @@ int pbrt_ctx_destroy(pbrt_ctx *c) {
 }
 
 const char *pbrt_last_error(pbrt_ctx *c) { return c ? c->err.c_str() : g_ctxless_error.c_str(); }
+
+int pbrt_ctx_set_workspace_limit(pbrt_ctx *c, uint64_t bytes) {
+    if (!c) return PBRT_E_INVALID;
+    c->ws_limit = (size_t)bytes;
+    return PBRT_OK;
+}
+
+// frees every workspace buffer the most recent call did not use, and every one that is larger than that call needed
+int pbrt_ctx_trim(pbrt_ctx *c, uint64_t *held_after) {
+    if (!c) return PBRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto it = c->ws.begin(); it != c->ws.end();) {
+        DevBuf &b = it->second;
+        const size_t fit = b.need < (size_t(64) << 20) ? b.need + b.need / 8 + 256 : b.need + 256;
+        if (b.stamp != c->call_seq || b.bytes > fit || !b.p) {
+            if (b.p) (void)hipFree(b.p);
+            it = c->ws.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    c->stats.workspace_bytes = c->ws_total();
+    if (held_after) *held_after = c->stats.workspace_bytes;
+    return PBRT_OK;
+}
 
 int pbrt_get_stats(pbrt_ctx *c, pbrt_stats *out) {
     if (!c || !out) return PBRT_E_INVALID;
@@ -911,35 +966,57 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // less in larger passes): ring 1024^2 x 64: 1 / 2 / 4 / 8 / 16 / 32 / 64 Mi -> 50.8 / 37.6 / 25.5 / 22.2 / 19.6 / 18.0 / 17.3 ms;
     // 64 Mi paths = 23 GB of workspace (356 B per path in flight); the fused BVH kernels (PBRT_FILM_NO_HIT_POOL) keep 16 Mi
     const bool wf_scene = !brute_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
-    // and beyond: 1024^2 x 512: 64 / 128 / 256 Mi -> 144 / 134 / 115 ms.  Default: the largest power of two whose workspace
-    // (WF_BYTES_PER_PATH per path in flight) fits 40 % of the free device memory, 16 .. 256 Mi (95 GB of the 288 GB of an MI355X)
+    // and beyond: 1024^2 x 512: 64 / 128 / 256 Mi -> 144 / 134 / 115 ms.  Default for BVH scenes: the largest power of two whose
+    // workspace (WF_BYTES_PER_PATH = 356 B per path in flight, allocated as asked) fits 40 % of the free device memory and the
+    // context's workspace limit, 1 .. 256 Mi (95.6 GB of the 288 GB of an MI355X at 256 Mi).  The free-memory figure is a snapshot
+    // (another process may allocate between the query and the hipMalloc), so a failed allocation halves the pass and tries again.
+    ++c->call_seq;
+    const uint64_t WF_MIN_PASS = 1u << 20;
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (64u << 20) : (16u << 20));
     if (!f->pass_paths && wf_scene) {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        for (const DevBuf *b : {&c->ws["wf_stateA"], &c->ws["wf_stateB"], &c->ws["wf_shadowA"], &c->ws["wf_shadowB"], &c->ws["wf_hits"],
-                                &c->ws["wf_hit_id"], &c->ws["Lhome"]})
-            free_b += b->bytes;  // what this context already holds is re-used, not allocated on top
-        pass_paths = 16u << 20;
-        while (pass_paths < (256u << 20) && 2 * pass_paths * WF_BYTES_PER_PATH <= (uint64_t)(0.4 * (double)free_b)) pass_paths *= 2;
+        size_t held = 0;  // what this context already holds for these buffers is re-used, not allocated on top
+        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hits", "wf_hit_id", "Lhome"}) {
+            auto it = c->ws.find(nm);
+            if (it != c->ws.end()) held += it->second.bytes;
+        }
+        double budget = 0.4 * (double)(free_b + held);
+        if (c->ws_limit) budget = std::min(budget, (double)c->ws_limit - (double)(c->ws_total() - held) - 64e6 /* the small buffers */);
+        pass_paths = WF_MIN_PASS;
+        while (pass_paths < (256u << 20) && 2.0 * (double)pass_paths * WF_BYTES_PER_PATH <= budget) pass_paths *= 2;
+    } else if (!f->pass_paths && c->ws_limit) {
+        // brute-force scenes under a workspace limit: 16 B of radiance record per path, and the ping-pong state (2 x 60 B) if the
+        // launch plan turns out to need it
+        const double budget = (double)c->ws_limit - 64e6;
+        while (pass_paths > WF_MIN_PASS && (double)pass_paths * (16 + 2 * N_STATE * 4) > budget) pass_paths /= 2;
     }
-    uint32_t s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
-    s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
-    NEED(c, npix_r * s_pass < 0xfffffc00ull);
-    const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
-    const uint32_t cap = div_up(npix_r * s_pass, REGION) * REGION;
-    const uint32_t nseg = cap / REGION;  // regions (one workgroup each)
-    NEED(c, wf_scene || (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the tiled state arrays are addressed through 32-bit buffer offsets
     // BVH scenes: intersection and shading as separate streams (kernels_wavefront.h); PBRT_FILM_NO_HIT_POOL keeps the fused
     // k_bounce (one launch per bounce, shading in the lanes the traversal leaves) as the A/B reference
     const bool bvh_scene = s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS;
     const bool wavefront = bvh_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
     static_assert(WF_REGION == REGION_SEGS_BVH * SEG_BVH, "both BVH launch structures cut a pass into the same regions");
+    const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
+    uint32_t s_pass = 1, cap = 0, nseg = 0;
     WfBufs wfb{};
     WfPlan wfp;
+    float *Lhome = nullptr;
+    for (;;) {
+        s_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(f->spp, pass_paths / std::max<uint64_t>(npix_r, 1)));
+        s_pass = div_up(f->spp, div_up(f->spp, s_pass));  // equal passes instead of full ones plus a small remainder
+        NEED(c, npix_r * s_pass < 0xfffffc00ull);
+        cap = div_up(npix_r * s_pass, REGION) * REGION;
+        nseg = cap / REGION;  // regions (one workgroup each)
+        NEED(c, wf_scene || (uint64_t)cap * N_STATE * 4 < 0xffffffffull);  // the tiled state arrays are addressed through 32-bit buffer offsets
+        if (wavefront) NEED(c, cap < WF_DEAD);  // ray records are addressed with two flag bits on top
+        Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
+        if (Lhome && (!wavefront || wf_alloc(c, cap, nseg, &wfb))) break;
+        // out of memory (or over the context's limit): give the pass buffers back and try with half the paths in flight
+        if (f->pass_paths || s_pass <= 1 || pass_paths <= WF_MIN_PASS) return PBRT_E_NOMEM;
+        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hits", "wf_hit_id", "Lhome"}) c->release(nm);
+        pass_paths = std::max<uint64_t>(WF_MIN_PASS, std::min<uint64_t>(pass_paths, npix_r * s_pass) / 2);
+    }
     if (wavefront) {
-        NEED(c, cap < WF_DEAD);  // ray records are addressed with two flag bits on top
-        if (!wf_alloc(c, cap, nseg, &wfb)) return PBRT_E_NOMEM;
         wfp = wf_plan(s);
         if ((rc = wf_set_attr(s, wfp)) != 0) return rc;
     }
@@ -948,7 +1025,6 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // is allocated per pass, for the paths of THAT pass, when its plan says so (state_for below).
     float *stA = wavefront ? (float *)wfb.stA : nullptr;
     float *stB = wavefront ? (float *)wfb.stB : nullptr;
-    float *Lhome = (float *)c->buf("Lhome", (size_t)cap * 16);  // float4 (r, g, b, 0) per home
     // fused BVH kernels: the live paths are made dense again before every bounce of depth >= 2 (k_scan_owners / k_repack_copy)
     const bool repack = bvh_scene && !wavefront && rad_wave_private(s->accel_kernel) && !(f->flags & PBRT_FILM_NO_REPACK);
     float *stC = repack ? (float *)c->buf("stateC", (size_t)cap * N_STATE * 4) : nullptr;
@@ -1324,6 +1400,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
+    ++c->call_seq;
     const uint32_t REGION = rad_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up(n, REGION) * REGION, nseg = cap / REGION;
     if (s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS) {  // trace / shade streams
@@ -1494,6 +1571,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
+    ++c->call_seq;
     const uint32_t NA = p->n_angles, NE = p->n_elements, T = p->time_samples;
     const uint32_t n_rays = NA * NE;
     std::vector<float> tx(n_rays), dir0(3 * NA), ex(NE);
@@ -1525,7 +1603,9 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
 // shading frame: 1.96 segments per path; three workgroups per CU): 4 / 8 / 16 / 32 Mi -> 13.26 / 11.89 / 11.61 / 12.20 ms
 #define US_PASS_PATHS (16u << 20)
 #endif
-    const uint64_t pass_paths = US_PASS_PATHS;
+    uint64_t pass_paths = US_PASS_PATHS;
+    if (c->ws_limit)  // two state buffers of N_STATE dwords per path in flight must fit the context's workspace limit
+        while (pass_paths > (1u << 20) && (double)pass_paths * (2 * N_STATE * 4) > (double)c->ws_limit - 64e6) pass_paths /= 2;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
     const uint32_t REGION = us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
@@ -1704,6 +1784,7 @@ struct Stage {
     size_t off = 0, cap = 0;
     int rc = PBRT_OK;
     Stage(pbrt_ctx *ctx, const char *name, size_t bytes) : c(ctx) {
+        ++c->call_seq;
         base = (char *)c->buf(name, bytes + 1024);
         cap = bytes + 1024;
         if (!base) rc = PBRT_E_NOMEM;

@@ -75,18 +75,29 @@ def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=N
     return tile, layout
 
 
-def gather_film(tile, layout, width, height, rank, world_size, group=None, force_collective=False):
+def gather_buffers(tile, rank, world_size, force_collective=False):
+    """The gather list of rank 0 (one tensor per rank, shaped like `tile`), to be allocated ONCE and handed to every
+    gather_film call of a loop; None on the other ranks and when no collective runs."""
+    import torch
+
+    if (world_size == 1 and not force_collective) or rank != 0:
+        return None
+    return [torch.empty_like(tile) for _ in range(world_size)]
+
+
+def gather_film(tile, layout, width, height, rank, world_size, group=None, force_collective=False, parts=None):
     """One gather of every rank's tile to rank 0, then de-interleave.  -> [H, W, 3] tensor on rank 0, None elsewhere.
     force_collective: issue the gather even at world_size 1 (a process group must be initialised): runs the collective
-    library on a box with one GPU."""
+    library on a box with one GPU.  parts: rank 0's gather list from gather_buffers (allocated per call when None)."""
     import torch
 
     dist = _dist()
     if world_size == 1 and not force_collective:
         parts = [tile]
     else:
-        parts = [torch.empty_like(tile) for _ in range(world_size)] if rank == 0 else None
-        dist.gather(tile, gather_list=parts, dst=0, group=group)
+        if rank == 0 and (parts is None or len(parts) != world_size or parts[0].shape != tile.shape or parts[0].device != tile.device):
+            parts = gather_buffers(tile, rank, world_size, force_collective=True)
+        dist.gather(tile, gather_list=parts if rank == 0 else None, dst=0, group=group)
         if rank != 0:
             return None
     film = torch.empty((height, width, 3), dtype=tile.dtype, device=tile.device)
@@ -112,12 +123,15 @@ def distributed_render(scene, spp, seed=0, band_rows=64, render_band=None, devic
 
 
 def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None, group=None, apply_pulse=None,
-                        on_call=None, host_collective=False, force_collective=False):
+                        on_call=None, host_collective=False, force_collective=False, timing=None):
     """Ultrasound: every rank traces its path range into its own (already normalised) channel buffer;
     one reduce(sum) to rank 0.  acquire(offset, count, norm, out_tensor) fills the tensor; the default
     calls the HIP library on the tensor's device memory.  With pulse_model 'gaussian' rank 0 convolves the reduced
     buffer with the pulse (apply_pulse: None = follow the integrator, False = never, True / callable = do it).
+    timing: a dict that receives this rank's work_s (acquisition) and collective_s (the reduce, incl. the wait for the others).
     -> [n_angles, n_elements, T] tensor on rank 0."""
+    import time
+
     import torch
 
     dist = _dist()
@@ -125,6 +139,7 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
+    t_a = time.perf_counter()
     ui = scene.integrator()
     off, cnt = path_ranges(paths_per_ray, world)[rank]
     dev = device if device is not None else torch.device("cpu")
@@ -139,10 +154,18 @@ def distributed_acquire(scene, paths_per_ray, seed=0, acquire=None, device=None,
                         out_dev=buf.data_ptr(), pulse=False)
             if on_call is not None:
                 on_call()
+    if buf.is_cuda:
+        torch.cuda.synchronize()
+    t_b = time.perf_counter()
     if world > 1 or (force_collective and dist.is_initialized()):
         if host_collective:  # gloo rehearsal on one GPU: the collective runs on host tensors
             buf = buf.cpu()
         dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=group)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+    if timing is not None:
+        timing["work_s"] = t_b - t_a
+        timing["collective_s"] = time.perf_counter() - t_b
     if rank != 0:
         return None
     if apply_pulse is None:

@@ -93,4 +93,5 @@ def test_invalid_arguments_return_error_codes(capi):
     assert lib.pbrt_scene_create(None, None, None) == -1
     assert lib.pbrt_render_radiance(None, None, None, None) == -1
     assert lib.pbrt_ray_intersect(None, 0, None, None, None, None, None, None, None) == -1
+    assert lib.pbrt_ctx_set_workspace_limit(None, 0) == -1 and lib.pbrt_ctx_trim(None, None) == -1
     assert lib.pbrt_ctx_destroy(None) == 0 and lib.pbrt_scene_destroy(None) == 0

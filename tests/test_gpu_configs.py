@@ -114,6 +114,10 @@ def test_bench_multi_gpu_rehearsal_launches_itself(tmp_path):
     assert "interleaved 64-row bands" in out["config"]["workload"] and out["config"]["baseline_config"] == 5
     assert out["rehearsal"]["stitched_equals_unsharded"] is True
     assert out["config"]["samples_per_step"] == 4096 * 4096 * 4 and out["value"] > 0
+    # every rank's own render and collective time rides on rank 0's line (an imbalance must be readable from the record)
+    assert len(out["per_rank_ms"]) == 2 and len(out["collective_ms"]) == 2 and all(t > 0 for t in out["per_rank_ms"])
+    assert out["gather_ms"] == out["collective_ms"][0]
+    assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] is not None
 
 
 def test_bench_rehearsal_of_the_ultrasound_split(tmp_path):

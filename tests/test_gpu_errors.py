@@ -105,3 +105,39 @@ def test_scenes_and_contexts_release_their_device_memory(mi):
     cycle(25)
     free1 = free_bytes()
     assert free0 - free1 < 64 << 20            # 50 scenes with a 100 KB - 30 MB footprint each would show
+
+
+def test_workspace_limit_and_trim(mi):
+    """ABI 4: under a workspace limit a BVH scene renders the SAME film in more, smaller passes; a limit below the smallest pass
+    is PBRT_E_NOMEM with a message (not a crash, not a silent truncation); pbrt_ctx_trim hands the memory back; without the limit
+    the context grows again.  (The reference's driver imports torch beside the renderer, USMain.py:5: two allocators, one GPU.)"""
+    ctx = mi.default_context()
+    sc = mi.load_file(scene_path("testring.xml"), res=256, spp=64)
+    try:
+        ctx.set_workspace_limit(0)
+        free = mi.render(sc, seed=3)
+        st_free = ctx.stats()
+        assert st_free["passes"] == 1 and st_free["workspace_bytes"] > 1_400_000_000      # 4 Mi paths x 356 B
+        ctx.set_workspace_limit(600 << 20)
+        assert ctx.trim() < 600 << 20                                                      # the 1.5 GB of the free render go back
+        capped = mi.render(sc, seed=3)
+        st = ctx.stats()
+        assert st["passes"] == 4 and st["pass_paths"] == 256 * 256 * 16
+        assert st["workspace_bytes"] <= 600 << 20
+        assert np.array_equal(free, capped)
+        # a brute-force scene and an acquisition under the same limit
+        cb = mi.load_file(scene_path("cbox.xml"), res=64, spp=8)
+        assert np.isfinite(mi.render(cb, seed=1)).all() and ctx.stats()["workspace_bytes"] <= 600 << 20
+        ctx.set_workspace_limit(50 << 20)
+        ctx.trim()
+        with pytest.raises(RuntimeError, match="workspace limit"):
+            mi.render(sc, seed=3)
+        ctx.set_workspace_limit(0)
+        again = mi.render(sc, seed=3)
+        assert np.array_equal(free, again) and ctx.stats()["passes"] == 1
+        held = ctx.stats()["workspace_bytes"]
+        small = mi.load_file(scene_path("testring.xml"), res=32, spp=1)
+        mi.render(small, seed=0)
+        assert ctx.trim() < held // 8                                                      # the large pass buffers are not kept for a small call
+    finally:
+        ctx.set_workspace_limit(0)

@@ -450,17 +450,19 @@ def _child_films(env, scene, res, spp, seed, pass_paths):
     return [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("film")]
 
 
-def test_bvh_passes_on_two_streams_render_the_same_film(mi):
-    """PBRT_WF_STREAMS=2 (opt-in): the halves of a pass's regions run on two streams, one phase apart -- a pass of 288 regions
-    (two streams need >= 256) and a two-pass render give the film of the one-stream default"""
+def test_bvh_passes_split_over_cu_masked_streams_render_the_same_film(mi):
+    """PBRT_WF_SPLIT=s:parts (opt-in, measured slower: DESIGN.md section 6): k_trace and k_shade run on two streams with disjoint CU
+    masks, the regions of a pass go through them in `parts` sets one phase apart -- a pass of 288 regions and a two-pass render give
+    the film of the one-stream default, and the launch count says the pipeline really ran"""
     import hashlib
     sc = mi.load_file(scene_path("testring.xml"), res=384, spp=8)
     want = [hashlib.sha256(sc.integrator().render(sc, seed=3, spp=8, pass_paths=pp).tobytes()).hexdigest() for pp in (0, 700_000)]
-    got = _child_films(dict(PBRT_WF_STREAMS="2"), "testring.xml", 384, 8, 3, (0, 700_000))
-    assert [g[0] for g in got] == want
     md = sc.integrator().max_depth
-    assert int(got[0][1]) == 1 and int(got[0][2]) == 4 * md      # one pass: two halves x (k_trace + k_shade) per bounce
-    assert int(got[1][1]) == 2
+    for spec, parts in (("2:2", 2), ("3:4", 4)):
+        got = _child_films(dict(PBRT_WF_SPLIT=spec), "testring.xml", 384, 8, 3, (0, 700_000))
+        assert [g[0] for g in got] == want, spec
+        assert int(got[0][1]) == 1 and int(got[0][2]) == 2 * parts * md, spec   # one pass: parts x (k_trace + k_shade) per bounce
+        assert int(got[1][1]) == 2
 
 
 @pytest.mark.parametrize("scene,res,spp", [("testring.xml", 201, 5), ("bunny.xml", 97, 3)])

@@ -219,12 +219,13 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         total_units = ui.n_angles * ui.n_elements * PPR
     scene.device()  # upload once, outside the timed region
     ctx = mi.default_context()
-    acc = dict(bounce_ms=0.0, bounce_bytes=0.0, kernel_ms=0.0, launches=0, segments=0, samples=0)
+    acc = dict(bounce_ms=0.0, bounce_bytes=0.0, trace_bytes=0.0, kernel_ms=0.0, launches=0, segments=0, samples=0)
 
     def account():
         st = ctx.stats()
         acc["bounce_ms"] += st["bounce_ms"]
         acc["bounce_bytes"] += st["bounce_model_bytes"]
+        acc["trace_bytes"] += st.get("trace_model_bytes", 0)
         acc["launches"] += st["bounce_launches"]
         acc["kernel_ms"] += st["kernel_ms"]
         acc["segments"] += st["segments"]
@@ -302,6 +303,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         value = total_units / (dt / steps) / 1e6
         achieved = (acc["bounce_bytes"] / 1e9) / (acc["bounce_ms"] / 1e3) if acc["bounce_ms"] > 0 else 0.0
         traffic, traffic_source = None, "not measured by this run (HBM bytes need separate rocprofv3 --pmc passes)"
+        traffic_by_kernel = None
         valu_busy = lane_active = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         src_hash = kernel_source_hash()
@@ -310,6 +312,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                 rec = json.load(open(pmc)).get(name)
                 if rec and rec.get("kernel_source_sha16") == src_hash:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_by_kernel = rec.get("traffic_over_algorithmic_by_kernel")
                     valu_busy = rec.get("valu_issue_busy")
                     lane_active = rec.get("lane_active")
                     traffic_source = f"profiles/pmc_traffic.json[{name}] recorded on these kernel sources ({src_hash}): {rec.get('how', '')}"
@@ -345,6 +348,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                          "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if (traffic and alg_per_launch) else None,
+                         "traffic_over_algorithmic_by_kernel": traffic_by_kernel,
                          "algorithmic_bytes_per_launch": round(alg_per_launch),
                          "avg_launch_ms": round(acc["bounce_ms"] / max(acc["launches"], 1), 5), "launches": acc["launches"],
                          "kernel_ms_per_step": round(acc["kernel_ms"] / steps, 3), "scope": "rank 0's launches of the timed steps",
@@ -365,6 +369,9 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                                        "lengths from the path survival of the scene's last render; Cornell box: one launch per pass), so the "
                                        "only HBM traffic left is one 16-byte radiance record per path (hbm_* keys)")
         if radiance and name == "testring":
+            # per step, so that the PMC bytes of the two kernel families (profiles/pmc_traffic.json) have their own denominators
+            out["roofline"]["algorithmic_bytes_per_step"] = {"k_trace_primary + k_trace": round(acc["trace_bytes"] / steps),
+                                                             "k_shade": round((acc["bounce_bytes"] - acc["trace_bytes"]) / steps)}
             out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
                                        "8 waves per SIMD; the camera rays: k_trace_primary, one tree walk per 64-path tile) and k_shade (full "
                                        "waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")

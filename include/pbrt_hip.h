@@ -278,6 +278,7 @@ typedef struct pbrt_stats {
     uint32_t plan_source;  /* PBRT_PLAN_* */
     uint64_t pass_paths;   /* paths in flight per pass */
     uint64_t workspace_bytes; /* device memory the context holds after the call */
+    uint64_t trace_model_bytes; /* ABI 4, BVH scenes: the part of bounce_model_bytes that belongs to the k_trace launches (the rest is k_shade's) */
 } pbrt_stats;
 #define PBRT_PLAN_CALLER 0u  /* pbrt_film_desc.flags carried PBRT_FILM_FUSE_PLAN */
 #define PBRT_PLAN_LEARNT 1u  /* from the path survival of the scene's previous render */

@@ -137,7 +137,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("bounce_ms", C.c_double), ("bounce_launches", C.c_uint32),
                 ("passes", C.c_uint32), ("model_bytes", C.c_uint64), ("bounce_model_bytes", C.c_uint64),
                 ("live", C.c_uint64 * 16), ("fuse_plan", C.c_uint32), ("plan_source", C.c_uint32),
-                ("pass_paths", C.c_uint64), ("workspace_bytes", C.c_uint64)]
+                ("pass_paths", C.c_uint64), ("workspace_bytes", C.c_uint64), ("trace_model_bytes", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

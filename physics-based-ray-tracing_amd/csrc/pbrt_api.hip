@@ -915,20 +915,32 @@ static int wf_check_guard(pbrt_ctx *c, const uint32_t *g) {
                    g[19], g[20], f[0], f[1], f[2], f[3], f[4], f[5], f[6], g[28], g[29], g[30]);
 }
 
-// Byte model of the two-launch bounce: k_trace reads 32 B per ray and writes a 16-B hit or a 4-B visibility;
-// k_shade reads the hit records, the state of the paths that hit something (64 B; the camera ray is regenerated at depth 0),
-// 32 B of the ones that did not, writes 64 B per survivor and per shadow ray, 16 B per path that ends, and applies a shadow
-// ray with 64 + 32 B.  live[d] = rays of depth d, hits[d] = those that hit something, shadows = shadow rays of the render.
-static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsigned long long *hits, uint32_t nd, uint64_t shadows) {
-    uint64_t b = 0;
+// Byte model of the two-launch bounce, the bytes the algorithm NEEDS, per depth d with live[d] rays of which
+// hits[d] hit something (both counted on the device), S = shadow rays of the render:
+//   k_trace (k_trace_primary at depth 0: the camera rays are generated in registers)
+//       32 B per continuation ray (origin, direction planes; depth >= 1), 4 B hit index, + 16 B hit record per hit
+//       per shadow ray: 32 B read + 4 B visibility written
+//   k_shade
+//       4 B hit index per ray, 16 B hit record per hit
+//       depth >= 1: the state of a path once -- 48 B (L / A / B planes) if its ray left the scene, all six planes (96 B) if it hit
+//       16 B radiance record per path that ends, 96 B per survivor, 32 B per shadow ray it emits
+// (the 64-byte primitive record and the vertex normals of a hit come from tables that stay in L2: 0 B.)  What the kernels move on
+// top of that -- the 48 bytes k_shade reads twice for a path that hit, whole 128-byte lines for sparse gathers -- is traffic, not
+// model: profiles/pmc_traffic.json has the ratio.  *trace = the part of the total that is k_trace's.
+static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsigned long long *hits, uint32_t nd, uint64_t shadows,
+                                      uint64_t *trace) {
+    uint64_t tr = 0, sh = 0;
     for (uint32_t d = 0; d < nd; ++d) {
-        const uint64_t in = live[d], next = d + 1 < nd ? live[d + 1] : 0, h = hits[d];
+        const uint64_t in = live[d], next = d + 1 < nd ? live[d + 1] : 0, h = std::min<uint64_t>(hits[d], in);
         if (!in) break;
-        b += (d > 0 ? in * 32 : 0) + in * 4 + h * 16;                     // k_trace: rays in, hit indices + hit records out
-        b += in * 4 + h * 16 + (d > 0 ? in * 48 + h * 96 : 0);            // k_shade: hit indices / records, state
-        b += (in - next) * 16 + next * 64;                                // radiance records, survivors
+        tr += (d > 0 ? in * 32 : 0) + in * 4 + h * 16;
+        sh += in * 4 + h * 16 + (d > 0 ? (in - h) * 48 + h * 96 : 0);
+        sh += (in - next) * 16 + next * 96;
     }
-    return b + shadows * (36 + 64 + 96);
+    tr += shadows * 36;
+    sh += shadows * 32;
+    if (trace) *trace = tr;
+    return tr + sh;
 }
 
 static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
@@ -1345,8 +1357,10 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
                          hit_pool ? hstats + HIT_ROW0 : nullptr, &tot, &bb);
     if (wavefront) {
         tot -= bb;
-        bb = wavefront_model_bytes(hstats + 2, hstats + HIT_ROW0, MAX_DEPTH_STATS, S.shadow_rays);
+        uint64_t trb = 0;
+        bb = wavefront_model_bytes(hstats + 2, hstats + HIT_ROW0, MAX_DEPTH_STATS, S.shadow_rays, &trb);
         tot += bb;
+        S.trace_model_bytes = trb;
     }
     if (brute_k && (f->flags & PBRT_FILM_REGEN)) {  // k_regen keeps the paths in registers: only the radiance records are written
         tot -= bb;

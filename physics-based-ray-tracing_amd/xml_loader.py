@@ -48,6 +48,10 @@ def _vec3(el, env, default=None):
 
 
 def _transform(el, env) -> ScalarTransform4f:
+    # Mitsuba: listed order, every new operation left-multiplies (M = op_n ... op_2 op_1).  transform_order="intent" (a
+    # load_file keyword) composes the other way round, M = op_1 op_2 ... op_n: the reading under which the phantoms of
+    # MitsubaScenes/*.xml, which list translate, rotate, scale, describe what USMain.py:69-71 builds (T @ R @ S).
+    intent = str(env.get("transform_order", "listed")) == "intent"
     m = np.eye(4)
     for op in el:
         a = {k: _subst(v, env) for k, v in op.attrib.items()}
@@ -71,7 +75,7 @@ def _transform(el, env) -> ScalarTransform4f:
                                   np.vstack([np.hstack([np.asarray(v).reshape(3, 3), np.zeros((3, 1))]), [0, 0, 0, 1]]))
         else:
             raise ValueError(f"unsupported transform operation <{op.tag}>")
-        m = t.matrix @ m
+        m = (m @ t.matrix) if intent else (t.matrix @ m)
     return ScalarTransform4f(m)
 
 

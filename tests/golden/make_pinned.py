@@ -2,7 +2,7 @@
 restatement written from the reference's Python -- NOT from oracle/oracle.cpp (see that module's header).
 
 Run in the build container (reads the reference's cbox OBJ quads as data):   python tests/golden/make_pinned.py
-Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k9_us_two_plates.npz, k9_us_two_plates_drjit.npz,
+Outputs, committed:  k9_us_plate.npz, k9_us_sphere_box.npz, k9_us_two_plates.npz, k9_us_two_plates_drjit.npz, k9_us_plate_box.npz,
                      k10_cbox_paths.npz, k11_meshes.npz, k12_emitter_sensor.npz
 
 K9  scenes:  'plate'       the scene USMain.py:26-90 builds (tilted plate 5 cm ahead, back wall at 1 m; integrator block :28-42)
@@ -88,6 +88,20 @@ US_SCENES = {
         shapes=[dict(type="rectangle", to_world=Tr(0.0075, 0, 0.02) @ Ry(180 + 12) @ Sc(0.003, 0.01, 1), impedance=7.8, roughness=0.7),
                 dict(type="rectangle", to_world=Tr(0, 0, 0.05) @ Ry(180) @ Sc(0.05, 0.05, 1), impedance=7.8, roughness=0.5)],
         seed=3, ppr=4),
+    # MitsubaScenes/Plate_Box.xml: integrator :2-15, plate :35-45, walls :46-100 (T @ R @ S): the tilted plate of Plane_Floating.xml
+    # inside the box of Sphere_Box.xml.  Reflections off the 45-degree plate go sideways to the walls and on: the fixture of the set
+    # with the longest chains (echoes deposited from the walls after two and three bounces)
+    "plate_box": dict(
+        params=dict(max_depth=10, fs=50e6, frequency=3e6, sound_speed=1480.0, attenuation=0.1, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        look_at=([0, 0, 0], [0, 0, 0.05], [0, 1, 0]),
+        shapes=[dict(type="rectangle", to_world=Tr(0, 0, 0.05) @ Ry(45) @ Sc(0.17, 0.17, 0.02), impedance=7.8, roughness=0.9),
+                dict(type="rectangle", to_world=Tr(0, 0, 0.37) @ Ry(180) @ Sc(0.15, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(-0.15, 0, 0.12) @ Ry(90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0.15, 0, 0.12) @ Ry(-90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
+        seed=5, ppr=3),
 }
 
 
@@ -312,6 +326,9 @@ def make_k12():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "k12":
         make_k12()
+        sys.exit(0)
+    if len(sys.argv) > 2 and sys.argv[1] == "k9":   # one ultrasound fixture: python make_pinned.py k9 plate_box
+        make_k9(sys.argv[2], US_SCENES[sys.argv[2]])
         sys.exit(0)
     for name, S in US_SCENES.items():
         make_k9(name, S)

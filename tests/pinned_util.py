@@ -123,6 +123,11 @@ def check_k9_records(z, meta, sample_fn):
     # sphere_box (roughness 0.9: every well-conditioned facet is past the 8.85 degree TIR angle) adds second bounces
     if meta["scene"] == "plate":
         assert z["rec_reflect"].sum() >= 8 and (~z["rec_reflect"]).sum() >= 4 and z["rec_tir"].sum() >= 4
+    elif meta["scene"] == "plate_box":
+        # MitsubaScenes/Plate_Box.xml: every path ends at its first bounce -- the plate is tilted by 45 degrees, so whatever the
+        # facet, the new direction leaves the 30-degree cut-off cone about the transducer normal (CustomIntegrator.py:368-372) and
+        # the five walls are never reached: 960 first-bounce echoes, none later (the fixture records that, it was not expected)
+        assert list(meta["depth_histogram"]) == ["0"] and z["rec_tir"].sum() >= 8
     else:
         assert (z["rec_depth"] >= 1).sum() >= 8 and z["rec_tir"].sum() >= 8
     if meta["scene"] == "two_plates":   # the scene whose second-bounce echoes are deposited

@@ -29,7 +29,11 @@ def check(buf, ref):
 
 @pytest.mark.parametrize("scene,ppr,seed,kw", [("us_plate.xml", 64, 0, {}), ("us_plate.xml", 500, 3, {}), ("us_sphere_box.xml", 200, 1, {}),
                                                ("us_cone_box.xml", 100, 2, {}),                          # analytic cone, brute force
-                                               ("us_cone_box.xml", 100, 2, dict(tessellate="true"))])    # 901 triangles, BVH
+                                               ("us_cone_box.xml", 100, 2, dict(tessellate="true")),     # 901 triangles, BVH
+                                               # the other phantoms of the reference's MitsubaScenes/ (author-intent transforms)
+                                               ("us_sphere_floating.xml", 150, 4, {}), ("us_plane_floating.xml", 150, 5, {}),
+                                               ("us_plate_box.xml", 150, 6, {}), ("us_cone_floating.xml", 150, 7, {}),
+                                               ("us_cone_floating.xml", 60, 8, dict(tessellate="true"))])
 def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed, kw):
     sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed, **kw)
     ui = sc.integrator()

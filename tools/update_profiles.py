@@ -1,7 +1,8 @@
 """copy the judged summaries of gpurun_out/prof_<tag>/ (tools/profile_bench.sh) into profiles/ and refresh the entry of
 profiles/pmc_traffic.json for one bench config.   usage: python tools/update_profiles.py <tag> <config> [fetch_factor]
-fetch_factor: known bytes / (FETCH_SIZE * 1024) measured by tools/pmc_calibrate.sh on k_bounce's own state access pattern
-(default 2.0, the guide's factor for wide streaming reads)."""
+fetch_factor: HBM bytes / (FETCH_SIZE * 1024) from tools/pmc_calibrate.sh -> profiles/<round>_pmc_calibration.json, which must
+exist (the entry cites it): 2.0 on every read pattern of these kernels -- 4-B and 16-B per lane streaming, 16-B records gathered
+by sorted slot lists of any density and by a permutation (the L2 fetches 128-byte lines, the counter tallies 64 per request)."""
 import csv, glob, json, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -12,6 +13,9 @@ fetch_factor = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
 write_factor = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
+calibration = f"profiles/{tag.split('_')[0]}_pmc_calibration.json"
+if not os.path.exists(os.path.join(root, calibration)):
+    sys.exit(f"{calibration} does not exist: run tools/pmc_calibrate.sh on the GPU box and copy gpurun_out/pmc_calibrate/calibration.json there first")
 shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, f"{tag}_rocprofv3_summary.txt"))
 shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{tag}_rocprofv3_summary.json"))
 ks = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
@@ -69,13 +73,29 @@ try:
     lane_active = round(sum(tc[k] * nt[k] for k in tc) / (64.0 * tot_a), 4) if tot_a else None
 except (ValueError, KeyError):
     pass
+# per kernel family: PMC bytes per bench step against the byte model of the same step (bench_under_rocprof.json carries the
+# model's split for BVH scenes); dispatches per step = dispatches of the two profiled steps / 2
+by_kernel = None
+try:
+    bj = json.load(open(b))
+    alg = bj["roofline"].get("algorithmic_bytes_per_step")
+    if alg:
+        steps_pmc = 2.0
+        fam_bytes = {}
+        for k in fetch:
+            fam = "k_shade" if k.startswith("k_shade") else "k_trace_primary + k_trace"
+            fam_bytes[fam] = fam_bytes.get(fam, 0.0) + (fetch_factor * fetch[k] + write_factor * write.get(k, 0.0)) * 1024 * nf[k] / steps_pmc
+        by_kernel = {fam: {"hbm_bytes_per_step": round(v), "algorithmic_bytes_per_step": alg[fam], "ratio": round(v / alg[fam], 3)}
+                     for fam, v in fam_bytes.items() if alg.get(fam)}
+except (OSError, KeyError, ValueError):
+    pass
 allrec[config] = {
-    "kernel": kernel, "hbm_bytes_per_launch": round(num / max(sum(nf.values()), 1)), "kernel_source_sha16": kernel_source_hash(),
+    "kernel": kernel, "calibration_file": calibration, "traffic_over_algorithmic_by_kernel": by_kernel, "hbm_bytes_per_launch": round(num / max(sum(nf.values()), 1)), "kernel_source_sha16": kernel_source_hash(),
     "valu_issue_busy": valu_busy, "lane_active": lane_active,
     "how": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --config {config} --steps 2 "
            f"--warmup 0 --no-cpu-baseline` (tools/profile_bench.sh {tag}); bytes = ({fetch_factor:g}*FETCH_SIZE + {write_factor:g}*WRITE_SIZE)*1024 "
-           f"per dispatch, averaged over the {kernel} dispatches; FETCH factor: tools/pmc_calibrate.sh on the kernel's own "
-           f"4-B-per-lane tiled row pattern (profiles/{tag.split('_')[0]}_pmc_calibration.json)",
+           f"per dispatch, averaged over the {kernel} dispatches; FETCH factor: tools/pmc_calibrate.sh on the kernels' own read "
+           f"patterns ({calibration})",
     "fetch_factor": fetch_factor, "write_factor": write_factor,
     "fetch_kib_per_dispatch": fetch, "write_kib_per_dispatch": write, "dispatches": nf, "tag": tag,
 }

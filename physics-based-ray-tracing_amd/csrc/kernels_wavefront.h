@@ -68,6 +68,7 @@ struct WfArgs {
     uint32_t index_offset, sample_index;
     uint32_t lds_bytes;          // ACCEL_K_BVH_LDS: bytes of the staged image
     uint32_t stk_rows, stk_shift;  // traversal stacks behind the image: rows, log2(threads of the workgroup)
+    uint32_t vis_q;              // plane of the path state whose .w takes a shadow ray's visibility (radiance: 4, ultrasound: 3)
     uint32_t *guard;             // WF_GUARD_WORDS words of the context: [0] waves that ran into the turn guard, [1..] state of one of them
 };
 
@@ -148,6 +149,9 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         cum[3 * K] = run;
         q_in = 0;
     }
+    __syncthreads();
+    const uint32_t total = cum[3 * K];
+    if (total == 0) return;  // uniform: nothing to trace (late bounces of an ultrasound pass), before the image is staged
     typename WfTree<ACCEL>::type tr;
     LDS_AS uint32_t *stk_lds = (LDS_AS uint32_t *)dyn_lds;
     if constexpr (ACCEL == ACCEL_K_BVH_LDS) {
@@ -155,11 +159,8 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         stk_lds += a.lds_bytes >> 2;
     } else {
         tr = TreeGlobal{a.sc.nodes, a.sc.lprims};
-        __syncthreads();
     }
     const BvhStack st = {stk_lds + tid, a.stk_shift, a.stk_rows};
-    const uint32_t total = cum[3 * K];
-    if (total == 0) return;  // uniform
 
     // A lane's state is its cursor: an inner node (>= 0) or a held leaf (bit 31 set) while its ray is being traced, BVH_SENT when
     // the ray has finished and waits to be retired, WF_IDLE when the lane has no ray.  The closest hit so far is (best, hu, hv,
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                 if (rslot & WF_DEAD)
                     reinterpret_cast<float *>(a.shd_in + 2u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;  // q2.w of the record
                 else
-                    reinterpret_cast<float *>(a.st_in + 4u * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // q4.w of the state
+                    reinterpret_cast<float *>(a.st_in + a.vis_q * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // .w of the state's visibility plane
             } else {
                 a.hit_id[rslot] = hid;
                 if (found) {

@@ -14,6 +14,7 @@
 #include "bvh_build.h"
 #include "kernels_us.h"
 #include "kernels_wavefront.h"
+#include "kernels_us_wavefront.h"
 #include "kernels_beamform.h"
 
 static std::string g_ctxless_error;
@@ -554,11 +555,14 @@ static int set_lds_attr(pbrt_scene *s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bounce<false, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-#endif
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<true, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_us_bounce<false, ACCEL_K_BVH_LDS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+#else
+    (void)c;
+    (void)bytes;
+#endif
     return PBRT_OK;
 }
 
@@ -738,6 +742,43 @@ static int wf_split_streams(pbrt_ctx *c, uint32_t s_cus) {
     return PBRT_OK;
 }
 
+// one k_trace / k_trace_primary launch over a.n_regions regions.  template arguments: <first bounce,> tree in LDS / in global
+// memory, scene with curved primitives
+static void wf_launch_trace(pbrt_scene *s, const WfArgs &a, const WfPlan &p, uint32_t G, bool first, hipStream_t st) {
+    const bool lds = s->accel_kernel == ACCEL_K_BVH_LDS;
+#define WF_TRACE(F, A, C) hipLaunchKernelGGL((k_trace<F, A, C>), dim3(G), dim3(p.threads), p.lds, st, a)
+#define WF_PRIMARY(A, C) hipLaunchKernelGGL((k_trace_primary<A, C>), dim3(G), dim3(1024), lds ? s->lds_bytes : 0u, st, a)
+    const int variant = (lds ? 2 : 0) | (s->curved ? 1 : 0);
+    if (first && p.packet) {
+        switch (variant) {
+            case 3: WF_PRIMARY(ACCEL_K_BVH_LDS, true); break;
+            case 2: WF_PRIMARY(ACCEL_K_BVH_LDS, false); break;
+            case 1: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, true); break;
+            default: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, false); break;
+        }
+    } else if (first) {
+        switch (variant) {
+            case 3: WF_TRACE(true, ACCEL_K_BVH_LDS, true); break;
+            case 2: WF_TRACE(true, ACCEL_K_BVH_LDS, false); break;
+            case 1: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, true); break;
+            default: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, false); break;
+        }
+    } else {
+        switch (variant) {
+            case 3: WF_TRACE(false, ACCEL_K_BVH_LDS, true); break;
+            case 2: WF_TRACE(false, ACCEL_K_BVH_LDS, false); break;
+            case 1: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, true); break;
+            default: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, false); break;
+        }
+    }
+#undef WF_TRACE
+#undef WF_PRIMARY
+}
+// workgroups of a k_trace launch over nr regions: at least nr / WF_KMAX (a workgroup walks at most WF_KMAX regions), else `mult` per CU
+static uint32_t wf_trace_grid(uint32_t nr, uint32_t mult, uint32_t cus) {
+    return std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * cus)));
+}
+
 // The bounces of one pass.  camera: depth 0 generates its rays from the film keys (else the rays are in b.stA / b.segA).
 // Returns the number of launches through *launches.
 static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p, uint32_t nreg, bool camera, uint32_t *launches) {
@@ -748,6 +789,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
     a.stk_shift = 0;
     while ((1u << a.stk_shift) < p.threads) ++a.stk_shift;
     if (!(a.guard = wf_guard(c))) return PBRT_E_NOMEM;
+    a.vis_q = 4;
     // the small shading tables in LDS when they fit (kernels_wavefront.h wf_tables_lds)
     const bool tabs = s->ds.n_mats <= TAB_MAX && s->ds.n_emitters <= TAB_MAX && s->ds.n_light_prims <= TAB_MAX;
     const WfSplit sp = wf_split_env();
@@ -793,36 +835,7 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         fill(depth, have_shadows, h);
         const uint32_t nr = regn[h];
         const uint32_t mult = depth >= 2 ? p.grid_deep : p.grid_mult;
-        const uint32_t G = std::min(nr, std::max(div_up(nr, WF_KMAX), std::max(1u, mult * cu_trace)));
-        hipStream_t st = st_t;
-        // template arguments: <first bounce,> tree in LDS / in global memory, scene with curved primitives
-#define WF_TRACE(F, A, C) hipLaunchKernelGGL((k_trace<F, A, C>), dim3(G), dim3(p.threads), p.lds, st, a)
-#define WF_PRIMARY(A, C) hipLaunchKernelGGL((k_trace_primary<A, C>), dim3(G), dim3(1024), lds ? s->lds_bytes : 0u, st, a)
-        const int variant = (lds ? 2 : 0) | (s->curved ? 1 : 0);
-        if (first && p.packet) {
-            switch (variant) {
-                case 3: WF_PRIMARY(ACCEL_K_BVH_LDS, true); break;
-                case 2: WF_PRIMARY(ACCEL_K_BVH_LDS, false); break;
-                case 1: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, true); break;
-                default: WF_PRIMARY(ACCEL_K_BVH_GLOBAL, false); break;
-            }
-        } else if (first) {
-            switch (variant) {
-                case 3: WF_TRACE(true, ACCEL_K_BVH_LDS, true); break;
-                case 2: WF_TRACE(true, ACCEL_K_BVH_LDS, false); break;
-                case 1: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, true); break;
-                default: WF_TRACE(true, ACCEL_K_BVH_GLOBAL, false); break;
-            }
-        } else {
-            switch (variant) {
-                case 3: WF_TRACE(false, ACCEL_K_BVH_LDS, true); break;
-                case 2: WF_TRACE(false, ACCEL_K_BVH_LDS, false); break;
-                case 1: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, true); break;
-                default: WF_TRACE(false, ACCEL_K_BVH_GLOBAL, false); break;
-            }
-        }
-#undef WF_TRACE
-#undef WF_PRIMARY
+        wf_launch_trace(s, a, p, wf_trace_grid(nr, mult, cu_trace), first, st_t);
         ++*launches;
     };
     auto shade = [&](uint32_t depth, bool first, bool have_shadows, uint32_t h) {
@@ -1554,7 +1567,7 @@ int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx) {
 }  // extern "C"
 
 template <bool FIRST>
-static void launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
+static int launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     hipStream_t st = s->ctx->stream;
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
@@ -1563,13 +1576,102 @@ static void launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
         case ACCEL_K_BRUTE_BIG:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
             break;
+#ifdef PBRT_DIAG  // the fused ultrasound bounce on BVH scenes (PBRT_US_FUSED_BVH=1): diagnostic build only
         case ACCEL_K_BVH_GLOBAL:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
             break;
         default:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
             break;
+#else
+        default:  // BVH scenes run k_trace / k_us_shade (us_wf_pass)
+            return s->ctx->fail(PBRT_E_UNSUPPORTED, "launch_us: no fused ultrasound bounce for accelerator %d in this build", s->accel_kernel);
+#endif
     }
+    return PBRT_OK;
+}
+
+// BVH scenes: the bounces of one ultrasound pass as k_trace / k_us_shade streams (kernels_us_wavefront.h).  a: the pass's UsArgs
+// (cap, n_paths, ppr_pass, path_first, tables set).  One launch at depth 0 with the first-bounce tables (else k_us_init_wf +
+// k_trace + k_us_shade), two per later bounce, and a flush for the occlusion rays of the last one.
+static int us_wf_pass(pbrt_scene *s, UsArgs a, const WfBufs &b, const WfPlan &p, uint32_t nreg, uint32_t *launches) {
+    pbrt_ctx *c = s->ctx;
+    hipStream_t st = c->stream;
+    WfArgs t{};
+    t.sc = s->ds;
+    t.cap = a.cap;
+    t.n_paths = a.n_paths;
+    t.key_mode = 0;
+    t.vis_q = US_WF_VIS_Q;
+    t.hits = b.hits;
+    t.hit_id = b.hit_id;
+    t.lds_bytes = s->accel_kernel == ACCEL_K_BVH_LDS ? s->lds_bytes : 0u;
+    t.stk_rows = p.rows;
+    t.stk_shift = 0;
+    while ((1u << t.stk_shift) < p.threads) ++t.stk_shift;
+    t.region0 = 0;
+    t.n_regions = nreg;
+    if (!(t.guard = wf_guard(c))) return PBRT_E_NOMEM;
+    UsWfArgs w{};
+    w.hits = b.hits;
+    w.hit_id = b.hit_id;
+    w.region0 = 0;
+    w.n_regions = nreg;
+    float4 *in = b.stA, *out = b.stB, *shi = b.shA, *sho = b.shB;
+    uint32_t *sin = b.segA, *sout = b.segB, *ni = b.nshA, *no = b.nshB;
+    auto trace = [&](uint32_t depth, bool have_shadows) {
+        t.depth = depth;
+        t.st_in = in;
+        t.shd_in = shi;
+        t.seg_in = sin;
+        t.nsh_in = have_shadows ? ni : nullptr;
+        wf_launch_trace(s, t, p, wf_trace_grid(nreg, depth >= 2 ? p.grid_deep : p.grid_mult, (uint32_t)c->n_cu), false, st);
+        ++*launches;
+    };
+    auto shade = [&](uint32_t depth, bool tab, bool have_shadows) {
+        a.depth = depth;
+        w.u = a;
+        w.st_in = in;
+        w.st_out = out;
+        w.shd_in = shi;
+        w.shd_out = sho;
+        w.seg_in = sin;
+        w.seg_out = sout;
+        w.nsh_in = have_shadows ? ni : nullptr;
+        w.nsh_out = no;
+        if (tab)
+            hipLaunchKernelGGL(k_us_shade<true>, dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, w);
+        else
+            hipLaunchKernelGGL(k_us_shade<false>, dim3(nreg), dim3(WF_SHADE_THREADS), 0, st, w);
+        ++*launches;
+    };
+    auto flip = [&]() {
+        std::swap(in, out);
+        std::swap(shi, sho);
+        std::swap(sin, sout);
+        std::swap(ni, no);
+    };
+    const bool tab = a.first_hit != nullptr && a.first_rx != nullptr;
+    if (tab) {
+        shade(0, true, false);
+    } else {
+        hipLaunchKernelGGL(k_us_init_wf, dim3(div_up(std::max(a.n_paths, nreg), 256)), dim3(256), 0, st, a, in, sin, nreg);
+        trace(0, false);
+        shade(0, false, false);
+    }
+    flip();
+    HIPCHK(c, hipGetLastError());
+    for (uint32_t depth = 1; depth < a.p.max_depth; ++depth) {
+        trace(depth, true);
+        shade(depth, false, true);
+        flip();
+        HIPCHK(c, hipGetLastError());
+    }
+    // the occlusion rays of the last bounce (every path has ended: records of ended paths only), and their echoes
+    trace(a.p.max_depth, true);
+    shade(a.p.max_depth, false, true);
+    HIPCHK(c, hipGetLastError());
+    return PBRT_OK;
 }
 
 extern "C" {
@@ -1617,25 +1719,50 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
 // shading frame: 1.96 segments per path; three workgroups per CU): 4 / 8 / 16 / 32 Mi -> 13.26 / 11.89 / 11.61 / 12.20 ms
 #define US_PASS_PATHS (16u << 20)
 #endif
-    uint64_t pass_paths = US_PASS_PATHS;
-    if (c->ws_limit)  // two state buffers of N_STATE dwords per path in flight must fit the context's workspace limit
-        while (pass_paths > (1u << 20) && (double)pass_paths * (2 * N_STATE * 4) > (double)c->ws_limit - 64e6) pass_paths /= 2;
+    // BVH scenes (tessellated phantoms, meshes) run as k_trace / k_us_shade streams (us_wf_pass); the diagnostic build keeps the
+    // fused bounce behind PBRT_US_FUSED_BVH=1 for the A/B
+    const bool bvh_scene = s->accel_kernel == ACCEL_K_BVH_GLOBAL || s->accel_kernel == ACCEL_K_BVH_LDS;
+    bool streams = bvh_scene;
+#ifdef PBRT_DIAG
+    if (const char *e = getenv("PBRT_US_FUSED_BVH")) streams = streams && atoi(e) == 0;
+#endif
+    // paths in flight per pass.  Streams: 2 x 10 launches per pass whatever is still alive, so larger passes (64 Mi; 356 B per path
+    // of the shared trace / shade workspace)
+    uint64_t pass_paths = streams ? (64u << 20) : US_PASS_PATHS;
+    const double per_path = streams ? (double)WF_BYTES_PER_PATH : (double)(2 * N_STATE * 4);
+    if (c->ws_limit)  // the pass buffers must fit the context's workspace limit
+        while (pass_paths > (1u << 20) && (double)pass_paths * per_path > (double)c->ws_limit - 64e6) pass_paths /= 2;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
-    const uint32_t REGION = us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
+    const uint32_t REGION = streams ? WF_REGION : us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
     const uint32_t cap = div_up((uint64_t)n_rays * ppr_pass, REGION) * REGION, nseg = cap / REGION;
-    NEED(c, (uint64_t)cap * US_N_STATE * 4 < 0xffffffffull);  // the state tiles are addressed through 32-bit buffer offsets
-    float *stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
-    float *stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
-    const uint32_t n_own = nseg * us_owners_per_region(s->accel_kernel);  // live counters / statistics rows
-    uint32_t *segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
-    uint32_t *segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
+    NEED(c, streams || (uint64_t)cap * US_N_STATE * 4 < 0xffffffffull);  // the state tiles are addressed through 32-bit buffer offsets
+    NEED(c, !streams || cap < WF_DEAD);
+    WfBufs wfb{};
+    WfPlan wfp;
+    float *stA = nullptr, *stB = nullptr;
+    uint32_t *segA = nullptr, *segB = nullptr;
+    if (streams) {
+        if (!wf_alloc(c, cap, nseg, &wfb)) return PBRT_E_NOMEM;
+        wfp = wf_plan(s);
+        wfp.packet = false;
+        if ((rc = wf_set_attr(s, wfp)) != 0) return rc;
+    } else {
+        stA = (float *)c->buf("stateA", (size_t)cap * N_STATE * 4);
+        stB = (float *)c->buf("stateB", (size_t)cap * N_STATE * 4);
+    }
+    // live counters / statistics rows: per region, per wave of a region for the BVH kernels
+    const uint32_t n_own = nseg * (streams ? WF_SHADE_THREADS / 64u : us_owners_per_region(s->accel_kernel));
+    if (!streams) {
+        segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
+        segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
+    }
     unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
     const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
     unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
     if (!segstats) return PBRT_E_NOMEM;
     float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
-    if (!stA || !stB || !segA || !segB || !dstats || !tabs) return PBRT_E_NOMEM;
+    if ((!streams && (!stA || !stB || !segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
     HIPCHK(c, hipMemcpyAsync(d_tx, tx.data(), (size_t)n_rays * 4, hipMemcpyHostToDevice, st));
@@ -1699,6 +1826,16 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         a.path_first = path_offset + k0;
         a.n_paths = n_rays * kc;
         const uint32_t nseg_pass = div_up(a.n_paths, REGION);
+        if (streams) {
+            pass_e1 = c->event(n_ev + 1);
+            hipEvent_t e0 = c->event(n_ev);
+            if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
+            n_ev += 2;
+            HIPCHK(c, hipEventRecord(e0, st));
+            if ((rc = us_wf_pass(s, a, wfb, wfp, nseg_pass, &launches)) != 0) return rc;
+            HIPCHK(c, hipEventRecord(pass_e1, st));
+            continue;
+        }
         float *in = stA, *out = stB;
         uint32_t *sin = segA, *sout = segB;
         for (uint32_t depth = 0; depth < p->max_depth; ++depth) {
@@ -1715,10 +1852,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
                 n_ev += 2;
                 HIPCHK(c, hipEventRecord(e0, st));
             }
-            if (depth == 0)
-                launch_us<true>(s, a, nseg_pass);
-            else
-                launch_us<false>(s, a, nseg_pass);
+            if ((rc = depth == 0 ? launch_us<true>(s, a, nseg_pass) : launch_us<false>(s, a, nseg_pass)) != 0) return rc;
             HIPCHK(c, hipGetLastError());
             ++launches;
             if (a.fuse) break;  // that launch walked every bounce (kernels_us.h)
@@ -1735,7 +1869,10 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
+    uint32_t hguard[WF_GUARD_WORDS] = {0};
+    if (streams && (rc = wf_guard_fetch(c, hguard)) != 0) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
+    if (streams && (rc = wf_check_guard(c, hguard)) != 0) return rc;
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;

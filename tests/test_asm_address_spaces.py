@@ -66,7 +66,8 @@ def test_the_stack_of_the_bvh_kernels_is_ds_rows_plus_scratch_overflow(asm):
     # closest-hit / any-hit leaf operators on a tree in global memory
     walkers = [k for k in kernels if re.match(r"_Z7k_traceILb[01]ELi[12]ELb[01]E", k) or re.match(r"_Z11k_us_bounceILb[01]ELi[12]E", k)
                or re.match(r"_Z(15k_ray_intersect|10k_ray_test)ILi1E", k)]
-    assert len(walkers) >= 8 + 4 + 2, walkers
+    # (the fused ultrasound bounce on BVH scenes lives in the diagnostic build only: the product runs k_trace + k_us_shade)
+    assert len(walkers) >= 8 + 2 + (4 if build == "diag" else 0), walkers
     for k in walkers:
         text = "\n".join(kernels[k])
         assert re.search(r"^\s+ds_write_b32\s", text, flags=re.M) and re.search(r"^\s+ds_read_b32\s", text, flags=re.M), k

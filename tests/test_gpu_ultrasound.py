@@ -33,7 +33,10 @@ def check(buf, ref):
                                                # the other phantoms of the reference's MitsubaScenes/ (author-intent transforms)
                                                ("us_sphere_floating.xml", 150, 4, {}), ("us_plane_floating.xml", 150, 5, {}),
                                                ("us_plate_box.xml", 150, 6, {}), ("us_cone_floating.xml", 150, 7, {}),
-                                               ("us_cone_floating.xml", 60, 8, dict(tessellate="true"))])
+                                               ("us_cone_floating.xml", 60, 8, dict(tessellate="true")),
+                                               # the ring of BASELINE config 4 as phantom (1157 primitives: k_trace + k_us_shade): with the
+                                               # first-bounce tables, and with fewer paths per ray than elements (primary rays traced)
+                                               ("us_testring.xml", 100, 9, {}), ("us_testring.xml", 24, 10, {})])
 def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed, kw):
     sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed, **kw)
     ui = sc.integrator()
@@ -206,7 +209,10 @@ def test_fused_bounces_change_nothing(mi, ob, capi, case):
     per_bounce = ui._acquire(sc, ui.quirks | capi.USQ_NO_FUSED_BOUNCES)
     st_p = mi.default_context().stats()
     assert st_f["live"] == st_p["live"] and st_f["segments"] == st_p["segments"]
-    assert st_f["bounce_launches"] == 1 and st_p["bounce_launches"] == ui.max_depth
+    if mesh:   # BVH scenes run k_trace / k_us_shade whatever the switch says: tables at depth 0, two launches per later bounce, a flush
+        assert st_f["bounce_launches"] == st_p["bounce_launches"] == 1 + 2 * (ui.max_depth - 1) + 2
+    else:
+        assert st_f["bounce_launches"] == 1 and st_p["bounce_launches"] == ui.max_depth
     assert np.array_equal(fused != 0, per_bounce != 0) and (fused != 0).sum() > 100
     assert np.allclose(fused, per_bounce, rtol=2e-5, atol=1e-7 * np.abs(per_bounce).max())
     if name == "stack":     # the loop really runs: paths alive at bounces 1, 2 and 3 -- and the oracle agrees
@@ -245,3 +251,40 @@ def test_exact_normal_incidence_is_nan_as_in_the_reference(mi, ob):
     got = ui._acquire(sc, ui.quirks).reshape(3, 32, 4000)
     ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), 9, 50)
     check(got, ref)
+
+
+@pytest.mark.parametrize("scene,kw", [("us_testring.xml", {}), ("us_cone_box.xml", dict(tessellate="true"))])
+def test_mesh_phantoms_as_streams_and_as_the_fused_bounce(mi, ob, capi, scene, kw):
+    """BVH scenes in ultrasound mode.  Product: k_trace (closest hits + the occlusion rays of the previous bounce) and k_us_shade
+    (the echo waits in the path state for its occlusion ray; a flush after the last bounce): equal to the oracle, the same with and
+    without the first-bounce tables, in several passes, and with the tree in global memory.  Diagnostic build, PBRT_US_FUSED_BVH=1:
+    the fused k_us_bounce on the same tree -- same echoes, same segment and per-depth path counts."""
+    import os
+    ppr = 192
+    sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=12, **kw)
+    ui = sc.integrator()
+    buf = ui._acquire(sc, ui.quirks)
+    st = mi.default_context().stats()
+    ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc), 12, ppr)
+    check(buf, ref)
+    assert st["bounce_launches"] == 1 + 2 * (ui.max_depth - 1) + 2          # tables at depth 0, two launches per later bounce, the flush
+    no_tab = ui._acquire(sc, ui.quirks | capi.USQ_NO_FIRST_TABLES)
+    st_nt = mi.default_context().stats()
+    check(no_tab, ref)
+    assert st_nt["bounce_launches"] == 2 * ui.max_depth + 2 and st_nt["segments"] == st["segments"] and list(st_nt["live"]) == list(st["live"])
+    halves = sum(ui._acquire(sc, ui.quirks, paths_per_ray=ppr // 2, path_offset=o, norm_paths=ppr).astype(np.float64) for o in (0, ppr // 2))
+    assert rel_l2(halves.astype(np.float32), ref) <= TOL_REL_L2
+    sc_g = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=12, **kw)
+    sc_g.accel = capi.ACCEL_BVH_GLOBAL
+    check(sc_g.integrator()._acquire(sc_g, ui.quirks), ref)
+    os.environ["PBRT_US_FUSED_BVH"] = "1"
+    try:
+        with capi.use_library(capi.DIAG_LIB_PATH):
+            sc_d = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=12, **kw)
+            fused = sc_d.integrator()._acquire(sc_d, ui.quirks)
+            st_f = mi.default_context().stats()
+            sc_d._dev = None
+    finally:
+        os.environ.pop("PBRT_US_FUSED_BVH", None)
+    check(fused, ref)
+    assert st_f["bounce_launches"] == 1 and st_f["segments"] == st["segments"] and list(st_f["live"]) == list(st["live"])

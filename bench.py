@@ -12,7 +12,7 @@ N > 1            BASELINE config 5: the same scene at 4096 x 4096, 1024 spp (17.
                  timed region; value = total samples / max-over-ranks time.  `--gpus N` without a torchrun environment
                  launches the ranks itself (python -m torch.distributed.run ..., as fresh child processes; the parent
                  never touches the GPU) and relays rank 0's JSON line.
---config NAME    cbox (config 2) | cbox4k (config 5) | us_sphere_box (config 3: MitsubaScenes/Sphere_Box.xml phantom,
+--config NAME    cbox (config 2) | cbox4k (config 5) | us_testring (the ring of config 4 as ultrasound phantom) | us_sphere_box (config 3: MitsubaScenes/Sphere_Box.xml phantom,
                  5 x 64 rays x 838 912 paths = 268 M transducer paths, ultrasound mode; N > 1: path ranges + one
                  reduce(sum)) | testring (config 4: TestRing/TestRing.obj, 1024 x 1024, 512 spp, LDS-resident BVH;
                  N > 1: bands + gather).  Default: cbox at N = 1, cbox4k at N > 1.
@@ -66,6 +66,9 @@ CONFIGS = {
     "testring": dict(kind="radiance", scene="testring.xml", res=1024, spp=512, max_depth=6, band_rows=0, baseline_config=4,
                      metric="Msamples/s on TestRing/TestRing.obj 1024x1024 x 512 spp (radiance, path max_depth 6, LDS-resident BVH)",
                      what="tent filter, TestRing.obj 1152 triangles + ground + area light"),
+    "us_testring": dict(kind="ultrasound", scene="us_testring.xml", ppr=838912, baseline_config=4,
+                        metric="Msamples/s on the TestRing.obj phantom (ultrasound twin of config 4), 5 x 64 rays x 838912 paths (UltraBSDF, max_depth 10, LDS-resident BVH)",
+                        what="TestRing.obj 1152 triangles + 5 walls, UltraBSDF, 5 angles x 64 elements, channel buffer 5 x 64 x 10000"),
     "us_sphere_box": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,
                           metric="Msamples/s on MitsubaScenes/Sphere_Box.xml phantom, 5 x 64 rays x 838912 paths (ultrasound, UltraBSDF, max_depth 10)",
                           what="sphere + 5 walls, UltraBSDF, 5 angles x 64 elements, channel buffer 5 x 64 x 10000"),
@@ -179,7 +182,7 @@ def main():
     if rank == 0 and world == 1 and args.config is None and not overridden and not args.no_also:
         # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line
         out["also"] = []
-        for other in ("us_sphere_box", "testring", "cbox4k"):
+        for other in ("us_sphere_box", "testring", "us_testring", "cbox4k"):
             o = measure(env, other, dict(CONFIGS[other]), 3, 1, seed=0, overridden=False, with_cpu=not args.no_cpu_baseline,
                         cpu_seconds=min(args.cpu_seconds, 6.0))
             keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline", "l2_vs_cpu_ref", "cpu_baseline", "config")
@@ -332,7 +335,8 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             workload = f"{cfg['scene']} ({cfg['what']}), {PPR} paths per ray; {sharding}"
         if overridden:
             workload += "  [SIZE OVERRIDDEN ON THE COMMAND LINE: not the named BASELINE workload]"
-        kernel = "k_us_bounce" if not radiance else ("k_trace_primary + k_trace + k_shade" if name == "testring" else "k_bounce")
+        kernel = (("k_trace + k_us_shade" if name == "us_testring" else "k_us_bounce") if not radiance
+                  else ("k_trace_primary + k_trace + k_shade" if name == "testring" else "k_bounce"))
         valu_frac = round(valu_busy * lane_active, 4) if (valu_busy is not None and lane_active is not None) else None
         alg_per_launch = acc["bounce_bytes"] / max(acc["launches"], 1)
         out = {
@@ -375,7 +379,10 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
                                        "8 waves per SIMD; the camera rays: k_trace_primary, one tree walk per 64-path tile) and k_shade (full "
                                        "waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")
-        if not radiance:
+        if not radiance and name == "us_testring":
+            out["roofline"]["note"] = ("ultrasound on a BVH scene: k_trace (closest hits + the unbounded occlusion rays towards the receive elements) "
+                                       "and k_us_shade per bounce; depth 0 comes from the first-bounce tables; SURVEY 8(d)'s 'natural extra' of config 4")
+        elif not radiance:
             out["roofline"]["note"] = ("k_us_bounce (GGX / impedance sample, expf, sinf, acosf; one launch walks every bounce of a pass)")
         if args.rehearse_on_one_gpu and world > 1:
             out["rehearsal"] = rehearsal_check(mi, np, scene, cfg, result, seed, world)

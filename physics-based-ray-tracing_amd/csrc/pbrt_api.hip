@@ -1898,6 +1898,28 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         bb += next * (N_USTATE * 4);
     }
     bb += hstats[0] * 8;  // one f32 atomic (read-modify-write) per shaded segment, upper bound
+    if (streams) {
+        // k_trace + k_us_shade (kernels_us_wavefront.h), the bytes the algorithm needs: per ray that is traced 32 B read + 4 B hit
+        // index written and read back, per hit a 16 B record written and read back; a path's pending echo (32 B) is read once,
+        // the rest of its state (32 B) if it hit; 64 B per survivor; an occlusion ray is 32 B written, 32 B read, 4 B answered.
+        // (With the first-bounce tables depth 0 traces and reads nothing.)  Occlusion rays: one per shaded segment at most.
+        const bool tab0 = a.first_hit != nullptr;
+        uint64_t tr = 0, sh = 0;
+        for (uint32_t d = 0; d < MAX_DEPTH_STATS; ++d) {
+            const uint64_t in = hstats[2 + d], next = d + 1 < MAX_DEPTH_STATS ? hstats[2 + d + 1] : 0;
+            if (!in) break;
+            if (d > 0 || !tab0) {
+                tr += in * (32 + 4);
+                sh += in * (4 + 32);
+            }
+            sh += next * 64;
+        }
+        const uint64_t seg = hstats[0], seg_traced = tab0 ? seg - std::min<uint64_t>(seg, hstats[2]) : seg;  // (every path of depth 0 hits or none of its ray does)
+        tr += seg_traced * 16 + seg_traced * 36;
+        sh += seg_traced * (16 + 32 + 32) + seg * 8;
+        bb = tr + sh;
+        S.trace_model_bytes = tr;
+    }
     S.bounce_model_bytes = bb;
     S.model_bytes = bb + nchan * 12;  // clear + scale pass over the channel buffer
     return PBRT_OK;

@@ -102,7 +102,40 @@ US_SCENES = {
                 dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
                 dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
         seed=5, ppr=3),
+    # the ultrasound twin of BASELINE config 4 (tests/scenes/us_testring.xml): the reference's TestRing/TestRing.obj (a data asset,
+    # read here from tests/scenes/meshes/) with its vertex normals, axis across the beam, in the box of Sphere_Box.xml.  The mesh
+    # case of the acquisition loop: Mesh::ray_intersect_triangle, interpolated shading normal, dp_du = p1 - p0
+    "testring": dict(
+        params=dict(max_depth=10, fs=50e6, frequency=3e6, sound_speed=1480.0, attenuation=0.1, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        look_at=([0, 0, 0], [0, 0, 0.05], [0, 1, 0]),
+        shapes=[dict(type="obj", filename="meshes/TestRing.obj", to_world=Tr(0, 0.025, 0.09) @ Rx(90), impedance=7.8, roughness=0.9),
+                dict(type="rectangle", to_world=Tr(0, 0, 0.37) @ Ry(180) @ Sc(0.15, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(-0.15, 0, 0.12) @ Ry(90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0.15, 0, 0.12) @ Ry(-90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
+        seed=13, ppr=3),
 }
+
+
+def read_obj(path):
+    """v / vn / f (v//vn) of a triangle OBJ -> vertices [nv, 3], triangles [nt, 3], per-triangle vertex normals [nt, 3, 3]"""
+    v, vn, tri, ntri = [], [], [], []
+    for ln in open(path):
+        t = ln.split()
+        if not t:
+            continue
+        if t[0] == "v":
+            v.append([float(x) for x in t[1:4]])
+        elif t[0] == "vn":
+            vn.append([float(x) for x in t[1:4]])
+        elif t[0] == "f":
+            ids = [tok.split("/") for tok in t[1:]]
+            assert len(ids) == 3
+            tri.append([int(i[0]) - 1 for i in ids])
+            ntri.append([int(i[2]) - 1 for i in ids])
+    return np.array(v), np.array(tri), np.array(vn)[np.array(ntri)]
 
 
 def build_shapes(desc):
@@ -111,6 +144,11 @@ def build_shapes(desc):
         bs = dict(impedance=d["impedance"], roughness=d["roughness"])
         if d["type"] == "sphere":
             out.append(rt.Sphere(d["center"], d["radius"], bsdf=bs))
+        elif d["type"] == "obj":   # Mitsuba `obj` shape under to_world: points by M, normals by the inverse transpose (a rotation here)
+            v, tri, vn = read_obj(os.path.join(HERE, "..", "scenes", d["filename"]))
+            M = np.asarray(d["to_world"], dtype=np.float64)
+            assert np.allclose(M[:3, :3] @ M[:3, :3].T, np.eye(3))
+            out.append(rt.TriMesh(v @ M[:3, :3].T + M[:3, 3], tri, bsdf=bs, vertex_normals=vn @ M[:3, :3].T))
         else:
             out.append(rt.Parallelogram.rectangle(d["to_world"], bsdf=bs))
     return out
@@ -162,7 +200,7 @@ def make_k9(name, S, variant="scalar"):
         bin_index=np.array(keys, np.int32).reshape(-1, 3), bin_pressure=np.array([bins[k]["p"] for k in keys]),
         bin_envelope=np.array([bins[k]["env"] for k in keys]), bin_envelope_abs=np.array([bins[k]["env_abs"] for k in keys]),
         bin_margin=np.array([bins[k]["margin"] for k in keys]), bin_count=np.array([bins[k]["n"] for k in keys], np.int32),
-        rec_wi=np.array([r["wi"] for r in pick]), rec_n=np.array([r["n"] for r in pick]), rec_sh_s=np.array([r["sh_s"] for r in pick]),
+        rec_wi=np.array([r["wi"] for r in pick]), rec_n=np.array([r["n"] for r in pick]), rec_sh_n=np.array([r["sh_n"] for r in pick]), rec_sh_s=np.array([r["sh_s"] for r in pick]),
         rec_s1=np.array([r["s1"] for r in pick]), rec_s2=np.array([r["s2"] for r in pick]), rec_wo=np.array([r["wo"] for r in pick]),
         rec_pdf=np.array([r["pdf"] for r in pick]), rec_a_resp=np.array([r["a_resp"] for r in pick]),
         rec_reflect=np.array([r["reflect"] for r in pick]), rec_tir=np.array([r["tir"] for r in pick]),

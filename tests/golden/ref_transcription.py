@@ -206,7 +206,7 @@ class TriMesh:
             qvec = np.cross(tvec, self.e1)
             v = (qvec @ d) * inv
             t = np.einsum("ij,ij->i", self.e2, qvec) * inv
-        ok = (det != 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0)
+            ok = (det != 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > 0)
         if not ok.any():
             return None
         tt = np.where(ok, t, np.inf)
@@ -353,7 +353,9 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
             break
         shape, (t, u, v, edge_margin) = hit
         p, n, dp_du = shape.interaction(ray_o, ray_d, t, u, v)
-        sh = sh_frame_from_dp_du(n, dp_du)                      # si.sh_frame (n = geometric = shading normal here)
+        # si.sh_frame.n: the geometric normal, except on a Mesh with vertex normals (Mesh::compute_surface_interaction interpolates them)
+        n_sh = shape.shading_normal(u, v) if isinstance(shape, TriMesh) else n
+        sh = sh_frame_from_dp_du(n_sh, dp_du)                   # si.sh_frame
         si_wi = sh.to_local(-ray_d)                             # SurfaceInteraction::finalize: wi = to_local(-ray.d)
         drjit = variant == "drjit"
         distance = t                                                                                # :314
@@ -370,14 +372,14 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
         tof_to_intersection = tof + distance / c_scalar if drjit else tof                           # drjit :165
         total_time = t0 + tof_to_intersection + math.sqrt(float((target_w - p) @ (target_w - p))) / c_scalar   # :329
         phase = 2.0 * math.pi * P["frequency"] * total_time                                         # :330
-        bs = ultra_bsdf_sample(shape.bsdf["impedance"], shape.bsdf["roughness"], si_wi, n, n, sh, s1, s2)   # :338
-        cos_theta = float(n @ -ray_d)                                                               # :340
+        bs = ultra_bsdf_sample(shape.bsdf["impedance"], shape.bsdf["roughness"], si_wi, n, n_sh, sh, s1, s2)   # :338
+        cos_theta = float(n_sh @ -ray_d)                                                            # :340 (si.sh_frame.n)
         amp *= bs["a_resp"] * cos_theta * max(bs["pdf"], 1e-6)                                      # :341
         # :345  directivity_weight_i(sec_dir, ...) * directivity_weight_o(ray.d, si.sh_frame.n, num_rays)
         alpha = abs(math.acos(max(-1.0, min(1.0, float(trans_normal_world @ -sec_dir)))))           # :293-295
         mid_cond = (alpha_c - alpha) / (alpha_c - alpha_m)                                          # :297
         w_i = 1.0 if alpha <= alpha_m else (mid_cond if alpha <= alpha_c else 0.0)                  # :299-302
-        w_o = float(ray_d @ n) / num_rays                                                           # :286-287
+        w_o = float(ray_d @ n_sh) / num_rays                                                        # :286-287 (si.sh_frame.n, :345)
         fd = w_i * w_o
         envelope = atten * amp * fd
         pressure_scalar = envelope * math.sin(phase)                                                # :348
@@ -411,7 +413,7 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
                      abs(u_recv * n_elements - round(u_recv * n_elements)) + (0.0 if 0 < round(u_recv * n_elements) < n_elements else 1.0))
         out.append(dict(depth=depth - 1, recv=recv_idx, t_idx=t_idx, visible=bool(visible), deposited=bool(deposited),
                         pressure=pressure_scalar, envelope=envelope, pdf=bs["pdf"], a_resp=bs["a_resp"], reflect=bs["reflect"],
-                        tir=bs["tir"], wi=si_wi.tolist(), n=n.tolist(), wo=bs["wo"].tolist(), new_dir=nd.tolist(), t=t,
+                        tir=bs["tir"], wi=si_wi.tolist(), n=n.tolist(), sh_n=n_sh.tolist(), wo=bs["wo"].tolist(), new_dir=nd.tolist(), t=t,
                         p=p.tolist(), amp=amp, atten=atten_before_rr, rr_prob=rr_prob, survive=bool(survive),
                         within=bool(within_angle), active=bool(active), s1=s1, s2=s2, margin=margin,
                         sh_s=sh.s.tolist(), sh_t=sh.t.tolist(), shape=[i for i, s_ in enumerate(shapes) if s_ is shape][0]))

@@ -74,6 +74,9 @@ def k9_scene(mi, meta):
         bs = {"type": "ultrasound_bsdf", "impedance": s["impedance"], "roughness": s["roughness"]}
         if s["type"] == "sphere":
             d[f"shape{i}"] = {"type": "sphere", "center": s["center"], "radius": s["radius"], "bsdf": bs}
+        elif s["type"] == "obj":
+            from conftest import scene_path
+            d[f"shape{i}"] = {"type": "obj", "filename": scene_path(s["filename"]), "to_world": T(np.asarray(s["to_world"])), "bsdf": bs}
         else:
             d[f"shape{i}"] = {"type": "rectangle", "to_world": T(np.asarray(s["to_world"])), "bsdf": bs}
     return mi.load_dict(d)
@@ -104,14 +107,18 @@ def check_k9_bins(z, meta, buf, carrier=True):
 
 
 def check_k9_records(z, meta, sample_fn):
-    """sample_fn(impedance, roughness, wi, n, sh_s, s1, s2) -> (wo [k,3], pdf [k], amp [k], lobe [k]) for one material"""
+    """sample_fn(impedance, roughness, wi, n, sh_s, s1, s2[, sh_n]) -> (wo [k,3], pdf [k], amp [k], lobe [k]) for one material
+    (sh_n: si.sh_frame.n where it differs from the geometric normal -- meshes with vertex normals; fixtures made since round 4)"""
     shapes = meta["shapes"]
     worst = 0.0
     for si in sorted(set(z["rec_shape"].tolist())):
         sel = z["rec_shape"] == si
+        extra = {}
+        if "rec_sh_n" in z.files and not np.array_equal(z["rec_sh_n"][sel], z["rec_n"][sel]):
+            extra["sh_n"] = z["rec_sh_n"][sel].astype(np.float32)
         wo, pdf, amp, lobe = sample_fn(shapes[si]["impedance"], shapes[si]["roughness"], z["rec_wi"][sel].astype(np.float32),
                                        z["rec_n"][sel].astype(np.float32), z["rec_sh_s"][sel].astype(np.float32),
-                                       z["rec_s1"][sel].astype(np.float32), z["rec_s2"][sel].astype(np.float32))
+                                       z["rec_s1"][sel].astype(np.float32), z["rec_s2"][sel].astype(np.float32), **extra)
         assert np.array_equal(lobe == 0, z["rec_reflect"][sel])
         assert np.allclose(pdf, z["rec_pdf"][sel], rtol=1e-4, atol=0)
         assert np.allclose(amp, z["rec_a_resp"][sel], rtol=1e-4, atol=1e-7)
@@ -123,6 +130,9 @@ def check_k9_records(z, meta, sample_fn):
     # sphere_box (roughness 0.9: every well-conditioned facet is past the 8.85 degree TIR angle) adds second bounces
     if meta["scene"] == "plate":
         assert z["rec_reflect"].sum() >= 8 and (~z["rec_reflect"]).sum() >= 4 and z["rec_tir"].sum() >= 4
+    elif meta["scene"] == "testring":
+        # the mesh phantom: second bounces inside the ring's wall (none of them seen by an element), shading normals on the cylinders
+        assert (z["rec_depth"] >= 1).sum() >= 8 and z["rec_tir"].sum() >= 8 and "rec_sh_n" in z.files
     elif meta["scene"] == "plate_box":
         # MitsubaScenes/Plate_Box.xml: every path ends at its first bounce -- the plate is tilted by 45 degrees, so whatever the
         # facet, the new direction leaves the 30-degree cut-off cone about the transducer normal (CustomIntegrator.py:368-372) and

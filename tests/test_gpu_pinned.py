@@ -10,20 +10,20 @@ from pinned_util import check_k10, check_k11, check_k9_bins, check_k9_records, k
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
 def test_k9_hip_single_bounce_records(mi, capi, name):
     """UltraBSDF.sample (CustomBSDF.py:87-175) through the plugin API -> pbrt_bsdf_sample"""
     z, meta = load_k9(name)
 
-    def sample(imp, rough, wi, n, sh_s, s1, s2):
+    def sample(imp, rough, wi, n, sh_s, s1, s2, sh_n=None):
         b = mi.UltraBSDF(mi.Properties("ultrasound_bsdf", dict(impedance=imp, roughness=rough)))
-        si = mi.SurfaceInteraction3f(wi, n=n, sh_n=n, sh_s=sh_s)
+        si = mi.SurfaceInteraction3f(wi, n=n, sh_n=n if sh_n is None else sh_n, sh_s=sh_s)
         bs, amp = b.sample(mi.BSDFContext(), si, s1, s2)
         return bs.wo, bs.pdf, amp, bs.sampled_component
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
 @pytest.mark.parametrize("tables", [True, False])
 def test_k9_hip_echo_values(mi, capi, name, tables):
     """the whole acquisition (CustomIntegrator.py:235-376): arrival bins, pressures and bare envelopes of every echo,

@@ -15,7 +15,7 @@ from pinned_util import SAFE, check_k10, check_k11, check_k9_bins, check_k9_reco
 sys.path.insert(0, GOLDEN)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
 def test_k9_fixture_is_what_the_transcription_produces(name):
     """the committed fixture equals a fresh run of the transcription (first rays of every angle)"""
     import make_pinned as mp
@@ -50,18 +50,18 @@ def test_rng_of_the_transcription_is_the_librarys(ob, capi):
     assert np.all((u >= 0) & (u < 1)) and len(np.unique(u)) == u.size
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
 def test_k9_oracle_single_bounce_records(ob, capi, name):
     z, meta = load_k9(name)
 
-    def sample(imp, rough, wi, n, sh_s, s1, s2):
+    def sample(imp, rough, wi, n, sh_s, s1, s2, sh_n=None):
         m = capi.make_material(capi.MAT_ULTRA, [imp, rough, 1.2])
-        wo, pdf, w, lobe = ob.bsdf_sample(m, capi.USQ_REFERENCE, wi, n, n, s1, np.stack([s2, s2], axis=1), sh_s=sh_s)
+        wo, pdf, w, lobe = ob.bsdf_sample(m, capi.USQ_REFERENCE, wi, n, n if sh_n is None else sh_n, s1, np.stack([s2, s2], axis=1), sh_s=sh_s)
         return wo, pdf, w[:, 0], lobe
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
 def test_k9_oracle_echo_values(mi, ob, capi, name):
     """every echo of every path: arrival bin, pressure (CustomIntegrator.py:340-354) and, with the carrier off, the
     envelope atten * amp * w_i * w_o alone; in two_plates the second-bounce echoes reach the receive elements (162 of

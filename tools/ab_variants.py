@@ -9,11 +9,12 @@ import pbrt_amd as mi
 scene, res, spp = os.environ.get("AB_SCENE", "tests/scenes/testring.xml"), int(os.environ.get("AB_RES", "1024")), int(os.environ.get("AB_SPP", "64"))
 if os.environ.get("AB_MODE") == "us":   # BASELINE config 3: the Sphere_Box phantom, 5 x 64 rays x 838 912 paths
     import numpy as np
-    us = mi.load_file(os.path.join(%r, "tests/scenes/us_sphere_box.xml"))
+    kw = dict(kv.split("=") for kv in os.environ.get("AB_US_KW", "").split(";") if kv)
+    us = mi.load_file(os.path.join(%r, os.environ.get("AB_US_SCENE", "tests/scenes/us_sphere_box.xml")), **kw)
     ui = us.integrator()
     best = 1e9
     for i in range(int(os.environ.get("AB_REPS", "3"))):
-        buf = ui._acquire(us, ui.quirks, paths_per_ray=838912, seed=0); st = mi.default_context().stats(); best = min(best, st["kernel_ms"])
+        buf = ui._acquire(us, ui.quirks, paths_per_ray=int(os.environ.get("AB_PPR", "838912")), seed=0); st = mi.default_context().stats(); best = min(best, st["kernel_ms"])
     print(f"{best:8.2f} ms  {st['samples']/best/1e3:7.0f} Msamples/s  |buf| {float(np.abs(buf).sum()):.9g} nonzero {int((buf != 0).sum())}", flush=True)
     sys.exit(0)
 sc = mi.load_file(os.path.join(%r, scene), res=res, spp=spp)

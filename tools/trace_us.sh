@@ -19,7 +19,7 @@ python3 - "$OUT" <<'PY'
 import csv, glob, os, sys
 f = max(glob.glob(os.path.join(sys.argv[1], "raw", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-rows = [r for r in rows if "k_us" in r["Kernel_Name"] or "k_scale" in r["Kernel_Name"] or "k_reduce" in r["Kernel_Name"]]
+rows = [r for r in rows if "k_us" in r["Kernel_Name"] or "k_trace" in r["Kernel_Name"] or "k_scale" in r["Kernel_Name"] or "k_reduce" in r["Kernel_Name"]]
 rows = rows[len(rows)//2:]
 t0 = int(rows[0]["Start_Timestamp"]); prev = None
 for i, r in enumerate(rows):

@@ -29,7 +29,6 @@
 struct UsWfArgs {
     UsArgs u;                       // scene, acquisition parameters, tables, channel buffer, statistics rows
     float4 *st_in, *st_out;         // [4][cap]
-    float4 *hits;
     uint32_t *hit_id;
     float4 *shd_in, *shd_out;       // [4][cap]
     const uint32_t *seg_in, *nsh_in;
@@ -169,11 +168,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
                 h.u = fh.y;
                 h.v = fh.z;
             } else {
-                const float4 hr = w.hits[base + s];
                 const float4 q0 = w.st_in[base + s], q1 = w.st_in[cp + base + s], q2 = w.st_in[2u * cp + base + s];
-                h.t = hr.x;
-                h.u = hr.y;
-                h.v = hr.z;
                 o = {q0.x, q0.y, q0.z};
                 amp = q0.w;
                 d = {q1.x, q1.y, q1.z};
@@ -189,6 +184,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
             const bool has_vn = a.sc.vnormals != nullptr;  // uniform
             WfVn vn;
             if (has_vn) vn = wf_load_vn(a.sc.vnormals, h.slot);
+            if (!TAB) (void)prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v);  // (t, u, v) of the hit k_trace found: kernels_wavefront.h k_shade
             const uint32_t depth = a.depth;
             const V3 tn = {uni[12], uni[13], uni[14]};
             const SI si = wf_make_si(P, o, d, h.t, h.u, h.v, has_vn, vn);

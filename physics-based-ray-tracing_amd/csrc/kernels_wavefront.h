@@ -5,14 +5,16 @@
 // once (96 - 128 VGPRs: 4 waves per SIMD beside the LDS image).  Here a bounce is two launches:
 //   k_trace  a STREAM of ray queries against the LDS-resident BVH4: the shadow rays the previous bounce emitted (any hit) and
 //            the continuation rays of the live paths (closest hit).  A lane whose ray has finished takes the next ray of the
-//            workgroup's queue -- the record of that ray was requested one refill earlier, so no lane waits on HBM -- and
-//            joins the two-phase walk of the others.  It reads 32 bytes per ray and writes 16 (hit) or 4 (visibility);
-//            nothing else is live, so two 1024-thread workgroups with their own image fit a CU (8 waves per SIMD).
-//   k_shade  every wave on its own, no barrier after the set-up: it reads the hit records of its 64-slot chunks, ends the
+//            workgroup's queue when enough lanes of its wave are idle (the other seven waves of the SIMD cover the load) and
+//            joins the two-phase walk of the others.  It reads 32 bytes per ray and writes 4: the index of the primitive that
+//            was hit, or the visibility; nothing else is live, so two 1024-thread workgroups with their own image fit a CU (8
+//            waves per SIMD).
+//   k_shade  every wave on its own, no barrier after the set-up: it reads the hit indices of its 64-slot chunks, ends the
 //            paths whose ray left the scene, keeps the slots of the others on a list of its own in LDS and shades 64 of them
-//            at a time with every lane busy: pending shadow contribution of the previous bounce, emission + MIS, emitter
-//            sample -> shadow record, BSDF sample, Russian roulette; survivors and shadow records are packed to the front of
-//            the region (ballot + one LDS atomic per wave).
+//            at a time with every lane busy: (t, u, v) of the hit from the primitive's record (the test k_trace made, repeated),
+//            pending shadow contribution of the previous bounce, emission + MIS, emitter sample -> shadow record, BSDF sample,
+//            Russian roulette; survivors and shadow records are packed to the front of the region (ballot + one LDS atomic
+//            per wave).
 // The contribution of a shadow ray is added where the fused kernel added it -- L = fma(A, B, L) before the next bounce touches
 // L -- so the film does not change by a bit: same arithmetic per path, same RNG keys, same order of the radiance sums.
 //
@@ -21,7 +23,7 @@
 // wave-instruction; only the state of the paths that hit something is gathered:
 //   path state, 96 B  q0 = (o, eta)  q1 = (d, prev_pdf)  q2 = (throughput, -)  q3 = (L, home)
 //                     q4 = (A, visibility of the path's shadow ray: written 0 by k_shade, set by k_trace)  q5 = (B, -)
-//   hit               hit_id[i] = primitive index | 0xffffffff: none (4 B, all a path that ends needs);  hits[i] = (t, u, v, -)
+//   hit               hit_id[i] = primitive index | 0xffffffff: none (4 B)
 //   shadow ray, 64 B  q0 = (origin, tmax)  q1 = (direction, dest)  and, for paths that ended at the bounce that emitted it,
 //                     q2 = (A, visibility)  q3 = (B, home); dest = state slot of the survivor | WF_DEAD | own record index.
 //                     Rays of survivors fill a region's records from the front, rays of ended paths from the back.
@@ -31,7 +33,7 @@
 #define WF_REGION 4096u      // slots per region (compaction domain of k_shade)
 #define WF_KMAX 21u          // regions one k_trace workgroup walks at most (three queue segments each)
 #ifndef WF_REFILL_MIN
-#define WF_REFILL_MIN 16u    // idle lanes that make a wave fetch new rays
+#define WF_REFILL_MIN 32u    // idle lanes that make a wave fetch new rays (ring 1024^2 x 256: 16 / 32 -> 48.9 / 48.1 ms)
 #endif
 #ifndef WF_WALK_MIN
 #define WF_WALK_MIN 16u      // the node walk of a turn stops when fewer lanes are still in it (while new rays can be had)
@@ -45,6 +47,9 @@
 #ifndef WF_SHADE_WAVES_PER_EU
 #define WF_SHADE_WAVES_PER_EU 5
 #endif
+// a wave whose walkers fall below WF_WALK_MIN stops walking to fetch rays: its idle lanes must then reach WF_REFILL_MIN (64 -
+// walkers, when no lane holds a leaf), or it would neither walk nor fetch (the turn guard caught exactly that with 48 / 32)
+static_assert(WF_REFILL_MIN + WF_WALK_MIN <= 65u, "k_trace: a wave below WF_WALK_MIN walkers must be able to refill");
 #define WF_DEAD 0x40000000u   // shadow ray of a path that has ended: dest = WF_DEAD | index of the ray's own record
 #define WF_SHADOW 0x80000000u
 #define WF_STATE_Q 6u         // float4s per path-state record
@@ -53,7 +58,6 @@ struct WfArgs {
     DevScene sc;
     pbrt_camera cam;
     float4 *st_in, *st_out;      // [cap][6] path state
-    float4 *hits;                // [cap] (t, u, v, -) of the rays that hit something
     uint32_t *hit_id;            // [cap] primitive index | 0xffffffff
     float4 *shd_in, *shd_out;    // [cap][4] shadow rays emitted by the previous / this bounce
     float *Lhome;                // [cap] float4 records (r, g, b, 0) indexed by home
@@ -103,7 +107,13 @@ DEV void wf_camera_ray(const WfArgs &a, uint32_t home, V3 *o, V3 *d, float *tmax
 // PBRT_E_DEVICE instead of hanging the box.  `turns` counts trips of the main loop and of the node walk; both loops are
 // wave-uniform, so it lives in a scalar register and every lane of the wave sees the trip.
 #define WF_GUARD_TURNS (1u << 22)
+#ifdef PBRT_WF_PROBE  // diagnostic builds: where do the lanes of k_trace go?  words 32.. of the guard buffer, printed by the host
+#define WF_GUARD_WORDS 64u
+#define WF_PROBE(i, v) probe[i] += (v)
+#else
 #define WF_GUARD_WORDS 32u
+#define WF_PROBE(i, v)
+#endif
 #define WF_IDLE 0xfffffffeu     // cursor of a lane without a ray (BVH_SENT = 0xffffffff: its ray has finished)
 #ifndef WF_WALK_UNROLL
 #define WF_WALK_UNROLL 1     // node visits between two looks at the wave's walkers (the refill test and the guard)
@@ -178,6 +188,9 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     bool q_empty = false;   // wave-uniform
     uint32_t s_hint = 0;    // wave-uniform: segment of the wave's last fetch (queue indices only grow)
     uint32_t turns = 0;     // wave-uniform (kept in a scalar register by the readfirstlane at its updates)
+#ifdef PBRT_WF_PROBE
+    unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] walk trips [1] lanes in them [2] leaf trips [3] lanes [4] main trips [5] rays fetched [6] lanes with a ray per main trip
+#endif
     for (;;) {
         if (turns > WF_GUARD_TURNS) {  // (uniform: the whole wave reports and leaves)
             const unsigned long long bb = __ballot(c.cur != WF_IDLE), bwk = __ballot((int32_t)c.cur >= 0);
@@ -219,6 +232,8 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             break;
         }
         turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)(turns + 1u));
+        WF_PROBE(4, 1);
+        WF_PROBE(6, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.cur != WF_IDLE)));
         // ---- retire
         if (c.cur == BVH_SENT) {
             const bool found = hid != 0xffffffffu;
@@ -230,10 +245,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
                     reinterpret_cast<float *>(a.st_in + a.vis_q * (size_t)a.cap + (rslot & 0x3fffffffu))[3] = vis;   // .w of the state's visibility plane
             } else {
                 a.hit_id[rslot] = hid;
-                if (found) {
-                    const float4 rec = {best, hu, hv, 0.0f};
-                    a.hits[rslot] = rec;
-                }
+
             }
             c.cur = WF_IDLE;
         }
@@ -250,6 +262,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
             if (i0 < total) {
                 while (s_hint + 1u < 3u * K && i0 >= cum[s_hint + 1u]) ++s_hint;  // uniform
             }
+            WF_PROBE(5, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.cur == WF_IDLE && i < total)));
             if (c.cur == WF_IDLE && i < total) {
                 uint32_t s = s_hint;
                 while (i >= cum[s + 1u]) ++s;
@@ -289,6 +302,8 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         for (;;) {
             const bool walking = (int32_t)c.cur >= 0;
             if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < walk_min) break;
+            WF_PROBE(0, 1);
+            WF_PROBE(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)));
             turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)(turns + WF_WALK_UNROLL));
             if (turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
             if (walking) bvh_visit(tr, st, c, ovf, br, best);
@@ -306,6 +321,8 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         for (uint32_t k = 0;; ++k) {
             const bool on = k < count;
             if (__builtin_amdgcn_ballot_w64(on) == 0ull) break;
+            WF_PROBE(2, 1);
+            WF_PROBE(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(on)));
             if (on) {
                 float t, u, v;
                 uint32_t id;
@@ -320,13 +337,17 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         }
         if (leaf) c.cur = (any && hid != 0xffffffffu) ? BVH_SENT : bvh_pop(tr, st, c, ovf);
     }
+#ifdef PBRT_WF_PROBE
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(reinterpret_cast<unsigned long long *>(a.guard + 32) + i, probe[i]);
+#endif
 }
 
 // ---- k_trace_primary ---------------------------------------------------------------------------------------------------------
 // The closest hits of the CAMERA rays (bounce 0 of a render): 64 consecutive paths are the 8 x 8 pixel tile of one sample
 // (path_key), so a wave walks the tree once for all of them (device_scene.h bvh_packet_closest) instead of 64 times with 64
 // stacks.  Same grid and region walk as k_trace (workgroup w: regions w, w + G, ...); the waves of a workgroup take the 64-path
-// tiles of those regions from a counter in LDS.  Writes hit_id / hits like k_trace; same hits, bit for bit.
+// tiles of those regions from a counter in LDS.  Writes hit_id like k_trace; same hits, bit for bit.
 // dynamic LDS: the image (ACCEL_K_BVH_LDS).
 template <int ACCEL, bool CURVED>
 __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(const WfArgs a) {
@@ -368,10 +389,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace_primary(c
         const bool found = bvh_packet_closest<CURVED>(tr, a.sc.prims, o, d, rep, best, hu, hv, hid);
         if (alive) {
             a.hit_id[slot] = found ? hid : 0xffffffffu;
-            if (found) {
-                const float4 rec = {best, hu, hv, 0.0f};
-                a.hits[slot] = rec;
-            }
+
         }
     }
 }
@@ -645,11 +663,11 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             Hit h;
             h.prim = wprim[wid][list_n + lane];
             h.slot = h.prim;
-            // one batch of loads: the hit, the primitive's record, its vertex normals, the path state
-            const float4 hr = a.hits[base + s];
-            h.t = hr.x;
-            h.u = hr.y;
-            h.v = hr.z;
+            // one batch of loads: the primitive's record, its vertex normals, the path state.  (t, u, v) of the hit are not carried
+            // through memory: k_trace hands over the primitive it found, and the test of THAT primitive against the ray is repeated
+            // here -- the same arithmetic on the same operands (a leaf record is the first nine floats of this record), so the same
+            // bits, for 60 VALU instructions of a kernel that waits on HBM instead of a 16-byte record written scattered (a 32-byte
+            // sector each) and gathered back (a 128-byte line each at the later bounces).
             const pbrt_prim P = wf_load_prim(tb.prims_by_slot + h.slot);
             const bool has_vn = a.sc.vnormals != nullptr;  // uniform
             WfVn vn;
@@ -675,6 +693,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);
             }
+            (void)prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v);
             survive = wf_shade_step<ACCEL_K_BVH_GLOBAL>(a, tb, a.depth, ka, kb, h, P, has_vn, vn, o, d, thr, L, eta, prev_pdf, sh);
         }
         n_seg_w += take;

@@ -686,15 +686,14 @@ static uint32_t *wf_guard(pbrt_ctx *c) {
     if (g && fresh && hipMemsetAsync(g, 0, WF_GUARD_WORDS * 4, c->stream) != hipSuccess) return nullptr;
     return g;
 }
-#define WF_BYTES_PER_PATH (2 * WF_STATE_Q * 16 + 16 + 4 + 2 * 64 + 16)  // two state sets, hit, hit index, two shadow sets, Lhome
+#define WF_BYTES_PER_PATH (2 * WF_STATE_Q * 16 + 4 + 2 * 64 + 16)  // two state sets, hit index, two shadow sets, Lhome
 struct WfBufs {
-    float4 *stA, *stB, *hits, *shA, *shB;
+    float4 *stA, *stB, *shA, *shB;
     uint32_t *hit_id, *segA, *segB, *nshA, *nshB;
 };
 static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
     b->stA = (float4 *)c->buf("wf_stateA", (size_t)cap * WF_STATE_Q * 16);
     b->stB = (float4 *)c->buf("wf_stateB", (size_t)cap * WF_STATE_Q * 16);
-    b->hits = (float4 *)c->buf("wf_hits", (size_t)cap * 16);
     b->hit_id = (uint32_t *)c->buf("wf_hit_id", (size_t)cap * 4);
     b->shA = (float4 *)c->buf("wf_shadowA", (size_t)cap * 64);
     b->shB = (float4 *)c->buf("wf_shadowB", (size_t)cap * 64);
@@ -702,7 +701,7 @@ static bool wf_alloc(pbrt_ctx *c, uint32_t cap, uint32_t nreg, WfBufs *b) {
     b->segB = (uint32_t *)c->buf("wf_segB", (size_t)nreg * 4);
     b->nshA = (uint32_t *)c->buf("wf_nshA", (size_t)nreg * 4);
     b->nshB = (uint32_t *)c->buf("wf_nshB", (size_t)nreg * 4);
-    return b->stA && b->stB && b->hits && b->hit_id && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
+    return b->stA && b->stB && b->hit_id && b->shA && b->shB && b->segA && b->segB && b->nshA && b->nshB;
 }
 // BVH scenes, opt-in (PBRT_WF_SPLIT=s[,parts]): the CUs are split between the two kernels of a bounce.  k_trace is bound by
 // instruction issue and k_shade by HBM, but run side by side on the same CUs they only trade wave slots (round 3: +2.8 %).  Here
@@ -820,7 +819,6 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         a.depth = depth;
         a.st_in = in;
         a.st_out = out;
-        a.hits = b.hits;
         a.hit_id = b.hit_id;
         a.shd_in = shi;
         a.shd_out = sho;
@@ -916,6 +914,16 @@ static int wf_guard_fetch(pbrt_ctx *c, uint32_t *host) {
     return PBRT_OK;
 }
 static int wf_check_guard(pbrt_ctx *c, const uint32_t *g) {
+#ifdef PBRT_WF_PROBE
+    {
+        unsigned long long pr[8];
+        std::memcpy(pr, g + 32, sizeof pr);
+        fprintf(stderr, "WF_PROBE walk trips %llu lanes %llu (%.3f) | leaf trips %llu lanes %llu (%.3f) | main trips %llu rays %llu busy lanes per trip %.1f\n",
+                pr[0], pr[1], pr[0] ? pr[1] / (64.0 * pr[0]) : 0.0, pr[2], pr[3], pr[2] ? pr[3] / (64.0 * pr[2]) : 0.0, pr[4], pr[5],
+                pr[4] ? (double)pr[6] / pr[4] : 0.0);
+        (void)hipMemsetAsync(wf_guard(c) + 32, 0, 64, c->stream);
+    }
+#endif
     if (g[0] == 0) return PBRT_OK;
     HIPCHK(c, hipMemsetAsync(wf_guard(c), 0, WF_GUARD_WORDS * 4, c->stream));
     float f[7];
@@ -931,10 +939,10 @@ static int wf_check_guard(pbrt_ctx *c, const uint32_t *g) {
 // Byte model of the two-launch bounce, the bytes the algorithm NEEDS, per depth d with live[d] rays of which
 // hits[d] hit something (both counted on the device), S = shadow rays of the render:
 //   k_trace (k_trace_primary at depth 0: the camera rays are generated in registers)
-//       32 B per continuation ray (origin, direction planes; depth >= 1), 4 B hit index, + 16 B hit record per hit
+//       32 B per continuation ray (origin, direction planes; depth >= 1), 4 B hit index written (the primitive, or none)
 //       per shadow ray: 32 B read + 4 B visibility written
 //   k_shade
-//       4 B hit index per ray, 16 B hit record per hit
+//       4 B hit index per ray ((t, u, v) are recomputed from the primitive's record, not read)
 //       depth >= 1: the state of a path once -- 48 B (L / A / B planes) if its ray left the scene, all six planes (96 B) if it hit
 //       16 B radiance record per path that ends, 96 B per survivor, 32 B per shadow ray it emits
 // (the 64-byte primitive record and the vertex normals of a hit come from tables that stay in L2: 0 B.)  What the kernels move on
@@ -946,8 +954,8 @@ static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsi
     for (uint32_t d = 0; d < nd; ++d) {
         const uint64_t in = live[d], next = d + 1 < nd ? live[d + 1] : 0, h = std::min<uint64_t>(hits[d], in);
         if (!in) break;
-        tr += (d > 0 ? in * 32 : 0) + in * 4 + h * 16;
-        sh += in * 4 + h * 16 + (d > 0 ? (in - h) * 48 + h * 96 : 0);
+        tr += (d > 0 ? in * 32 : 0) + in * 4;
+        sh += in * 4 + (d > 0 ? (in - h) * 48 + h * 96 : 0);
         sh += (in - next) * 16 + next * 96;
     }
     tr += shadows * 36;
@@ -1002,7 +1010,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
         size_t held = 0;  // what this context already holds for these buffers is re-used, not allocated on top
-        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hits", "wf_hit_id", "Lhome"}) {
+        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hit_id", "Lhome"}) {
             auto it = c->ws.find(nm);
             if (it != c->ws.end()) held += it->second.bytes;
         }
@@ -1038,7 +1046,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
         if (Lhome && (!wavefront || wf_alloc(c, cap, nseg, &wfb))) break;
         // out of memory (or over the context's limit): give the pass buffers back and try with half the paths in flight
         if (f->pass_paths || s_pass <= 1 || pass_paths <= WF_MIN_PASS) return PBRT_E_NOMEM;
-        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hits", "wf_hit_id", "Lhome"}) c->release(nm);
+        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hit_id", "Lhome"}) c->release(nm);
         pass_paths = std::max<uint64_t>(WF_MIN_PASS, std::min<uint64_t>(pass_paths, npix_r * s_pass) / 2);
     }
     if (wavefront) {
@@ -1603,7 +1611,6 @@ static int us_wf_pass(pbrt_scene *s, UsArgs a, const WfBufs &b, const WfPlan &p,
     t.n_paths = a.n_paths;
     t.key_mode = 0;
     t.vis_q = US_WF_VIS_Q;
-    t.hits = b.hits;
     t.hit_id = b.hit_id;
     t.lds_bytes = s->accel_kernel == ACCEL_K_BVH_LDS ? s->lds_bytes : 0u;
     t.stk_rows = p.rows;
@@ -1613,7 +1620,6 @@ static int us_wf_pass(pbrt_scene *s, UsArgs a, const WfBufs &b, const WfPlan &p,
     t.n_regions = nreg;
     if (!(t.guard = wf_guard(c))) return PBRT_E_NOMEM;
     UsWfArgs w{};
-    w.hits = b.hits;
     w.hit_id = b.hit_id;
     w.region0 = 0;
     w.n_regions = nreg;
@@ -1900,7 +1906,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     bb += hstats[0] * 8;  // one f32 atomic (read-modify-write) per shaded segment, upper bound
     if (streams) {
         // k_trace + k_us_shade (kernels_us_wavefront.h), the bytes the algorithm needs: per ray that is traced 32 B read + 4 B hit
-        // index written and read back, per hit a 16 B record written and read back; a path's pending echo (32 B) is read once,
+        // index written and read back; a path's pending echo (32 B) is read once,
         // the rest of its state (32 B) if it hit; 64 B per survivor; an occlusion ray is 32 B written, 32 B read, 4 B answered.
         // (With the first-bounce tables depth 0 traces and reads nothing.)  Occlusion rays: one per shaded segment at most.
         const bool tab0 = a.first_hit != nullptr;
@@ -1915,8 +1921,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
             sh += next * 64;
         }
         const uint64_t seg = hstats[0], seg_traced = tab0 ? seg - std::min<uint64_t>(seg, hstats[2]) : seg;  // (every path of depth 0 hits or none of its ray does)
-        tr += seg_traced * 16 + seg_traced * 36;
-        sh += seg_traced * (16 + 32 + 32) + seg * 8;
+        tr += seg_traced * 36;
+        sh += seg_traced * (32 + 32) + seg * 8;
         bb = tr + sh;
         S.trace_model_bytes = tr;
     }

@@ -153,7 +153,7 @@ typedef struct pbrt_film_desc {
     uint32_t flags;      /* PBRT_FILM_*                                                  */
     uint32_t pass_paths; /* 0 = library default; paths kept in flight per pass.  Default: 64 Mi for brute-force scenes
                             (8 B..120 B of workspace per path, by launch plan); BVH scenes (356 B per path) the largest power of
-                            two, 16 .. 256 Mi, whose workspace fits 40 % of the free device memory -- pbrt_stats reports both */
+                            two, 1 .. 512 Mi, whose workspace fits two thirds of the free device memory -- pbrt_stats reports both */
 } pbrt_film_desc;
 
 #define PBRT_FILM_RAW_ACCUM 1u /* output 4 floats/pixel (sum w*rgb, sum w) un-normalised: \
@@ -298,7 +298,8 @@ const char *pbrt_last_error(pbrt_ctx *ctx); /* ctx may be NULL: last ctx-less er
 int pbrt_get_stats(pbrt_ctx *ctx, pbrt_stats *out);
 /* Workspace policy (ABI 4).  A context keeps the device buffers of its calls (path state, ray and radiance records, film
  * accumulators) and re-uses them; pbrt_stats.workspace_bytes says how much it holds.  BVH scenes size a pass to the largest power
- * of two of paths (1 .. 256 Mi, 356 B each) that fits 40 % of the free device memory -- up to 95.6 GB on an idle MI355X.  A caller
+ * of two of paths (1 .. 512 Mi, 340 B each) that fits two thirds of the free device memory -- up to 183 GB on an idle MI355X
+ * (larger passes are faster: their twelve launches per pass fill the chip longer).  A caller
  * that shares the device (the reference's driver imports torch beside the renderer, USMain.py:5) bounds that with a limit -- here,
  * or PBRT_WORKSPACE_LIMIT_BYTES in the environment at pbrt_ctx_create; 0 = none -- and hands memory back with pbrt_ctx_trim.
  * Under a limit, and when an allocation fails, renders take smaller passes (same film, more passes); a request that cannot be met

@@ -905,6 +905,24 @@ static int wf_bounces(pbrt_scene *s, WfArgs a, const WfBufs &b, const WfPlan &p,
         for (uint32_t h = 0; h < parts; ++h) HIPCHK(c, hipStreamWaitEvent(c->stream, c->sync_ev[2u * h + 1u], 0));
     return PBRT_OK;
 }
+// Default paths in flight per pass of the trace / shade streams: the largest power of two (min_pass .. 512 Mi) whose workspace
+// (WF_BYTES_PER_PATH each) fits two thirds of the free device memory -- what this context already holds for these buffers is
+// re-used, not allocated on top -- and the context's workspace limit.
+static uint64_t wf_default_pass_paths(pbrt_ctx *c, uint64_t min_pass) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    size_t held = 0;
+    for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hit_id", "Lhome"}) {
+        auto it = c->ws.find(nm);
+        if (it != c->ws.end()) held += it->second.bytes;
+    }
+    double budget = (2.0 / 3.0) * (double)(free_b + held);
+    if (c->ws_limit) budget = std::min(budget, (double)c->ws_limit - (double)(c->ws_total() - held) - 64e6 /* the small buffers */);
+    uint64_t pass_paths = min_pass;
+    while (pass_paths < (512u << 20) && 2.0 * (double)pass_paths * WF_BYTES_PER_PATH <= budget) pass_paths *= 2;
+    return pass_paths;
+}
+
 // The guard words of the context come back with the statistics of a call (wf_guard_fetch queues the copy on the call's stream,
 // wf_check_guard looks at them once the stream has drained): did a wave of k_trace run into its turn guard?
 static int wf_guard_fetch(pbrt_ctx *c, uint32_t *host) {
@@ -1000,24 +1018,16 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // 64 Mi paths = 23 GB of workspace (356 B per path in flight); the fused BVH kernels (PBRT_FILM_NO_HIT_POOL) keep 16 Mi
     const bool wf_scene = !brute_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
     // and beyond: 1024^2 x 512: 64 / 128 / 256 Mi -> 144 / 134 / 115 ms.  Default for BVH scenes: the largest power of two whose
-    // workspace (WF_BYTES_PER_PATH = 356 B per path in flight, allocated as asked) fits 40 % of the free device memory and the
-    // context's workspace limit, 1 .. 256 Mi (95.6 GB of the 288 GB of an MI355X at 256 Mi).  The free-memory figure is a snapshot
+    // workspace (WF_BYTES_PER_PATH = 340 B per path in flight, allocated as asked) fits two thirds of the free device memory and
+    // the context's workspace limit, 1 .. 512 Mi (round 4, 1024^2 x 512: 128 / 256 / 512 Mi -> 105.9 / 99.5 / 94.6 ms; 512 Mi paths =
+    // 183 GB of the 288 GB of an MI355X -- a renderer that owns the device takes it; one that shares it sets a limit, see
+    // pbrt_ctx_set_workspace_limit, and pbrt_ctx_trim hands the memory back).  The free-memory figure is a snapshot
     // (another process may allocate between the query and the hipMalloc), so a failed allocation halves the pass and tries again.
     ++c->call_seq;
     const uint64_t WF_MIN_PASS = 1u << 20;
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (64u << 20) : (16u << 20));
     if (!f->pass_paths && wf_scene) {
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
-        size_t held = 0;  // what this context already holds for these buffers is re-used, not allocated on top
-        for (const char *nm : {"wf_stateA", "wf_stateB", "wf_shadowA", "wf_shadowB", "wf_hit_id", "Lhome"}) {
-            auto it = c->ws.find(nm);
-            if (it != c->ws.end()) held += it->second.bytes;
-        }
-        double budget = 0.4 * (double)(free_b + held);
-        if (c->ws_limit) budget = std::min(budget, (double)c->ws_limit - (double)(c->ws_total() - held) - 64e6 /* the small buffers */);
-        pass_paths = WF_MIN_PASS;
-        while (pass_paths < (256u << 20) && 2.0 * (double)pass_paths * WF_BYTES_PER_PATH <= budget) pass_paths *= 2;
+        pass_paths = wf_default_pass_paths(c, WF_MIN_PASS);
     } else if (!f->pass_paths && c->ws_limit) {
         // brute-force scenes under a workspace limit: 16 B of radiance record per path, and the ping-pong state (2 x 60 B) if the
         // launch plan turns out to need it
@@ -1732,12 +1742,11 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
 #ifdef PBRT_DIAG
     if (const char *e = getenv("PBRT_US_FUSED_BVH")) streams = streams && atoi(e) == 0;
 #endif
-    // paths in flight per pass.  Streams: 2 x 10 launches per pass whatever is still alive, so larger passes (64 Mi; 356 B per path
-    // of the shared trace / shade workspace)
-    uint64_t pass_paths = streams ? (64u << 20) : US_PASS_PATHS;
-    const double per_path = streams ? (double)WF_BYTES_PER_PATH : (double)(2 * N_STATE * 4);
-    if (c->ws_limit)  // the pass buffers must fit the context's workspace limit
-        while (pass_paths > (1u << 20) && (double)pass_paths * per_path > (double)c->ws_limit - 64e6) pass_paths /= 2;
+    // paths in flight per pass.  Streams: 2 x 10 launches per pass whatever is still alive, so passes as large as the radiance
+    // streams take (wf_default_pass_paths; the shared trace / shade workspace)
+    uint64_t pass_paths = streams ? wf_default_pass_paths(c, 1u << 20) : US_PASS_PATHS;
+    if (!streams && c->ws_limit)  // the pass buffers must fit the context's workspace limit
+        while (pass_paths > (1u << 20) && (double)pass_paths * (double)(2 * N_STATE * 4) > (double)c->ws_limit - 64e6) pass_paths /= 2;
     uint32_t ppr_pass = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(ppr, pass_paths / n_rays));
     NEED(c, (uint64_t)n_rays * ppr_pass < 0xfffffc00ull);
     const uint32_t REGION = streams ? WF_REGION : us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);

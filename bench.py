@@ -372,10 +372,11 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             out["roofline"]["note"] = ("the brute-force bounce kernels walk up to six bounces of a path in registers (the library picks the chain "
                                        "lengths from the path survival of the scene's last render; Cornell box: one launch per pass), so the "
                                        "only HBM traffic left is one 16-byte radiance record per path (hbm_* keys)")
-        if radiance and name == "testring":
+        if name in ("testring", "us_testring"):
             # per step, so that the PMC bytes of the two kernel families (profiles/pmc_traffic.json) have their own denominators
             out["roofline"]["algorithmic_bytes_per_step"] = {"k_trace_primary + k_trace": round(acc["trace_bytes"] / steps),
                                                              "k_shade": round((acc["bounce_bytes"] - acc["trace_bytes"]) / steps)}
+        if radiance and name == "testring":
             out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
                                        "8 waves per SIMD; the camera rays: k_trace_primary, one tree walk per 64-path tile) and k_shade (full "
                                        "waves, HBM-bound: 96-byte path state, 32-byte shadow rays, hit records)")

@@ -6,7 +6,7 @@
 #   3. --pmc WRITE_SIZE       : HBM write bytes  (separate pass: the two counters do not fit one)
 # Summaries land in gpurun_out/prof_<tag>/ ; tools/update_profiles.py <tag> <config> copies them into profiles/.
 set -o pipefail
-TAG=${1:-r03}; shift
+TAG=${1:-r04}; shift
 # one process per profiler: bench.py --gpus N > 1 would start its ranks as children of a process whose GPU the profiler's preloaded
 # library has already initialised (and the children would inherit the preload).  Profile multi-rank runs rank by rank instead.
 for a in "$@"; do case "$prev$a" in --gpus[2-9]*|--gpus=[2-9]*|--gpus1[0-9]*) echo "profile_bench.sh: --gpus > 1 is refused (see the comment)"; exit 2;; esac; prev=$a; done

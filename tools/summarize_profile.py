@@ -17,7 +17,7 @@ def find(sub, pat):
 
 def short(name):
     n = name.split("(")[0]
-    for k in ("k_bounce", "k_trace", "k_shade", "k_us_bounce", "k_film_accum", "k_film_resolve", "k_scale"):
+    for k in ("k_bounce", "k_trace", "k_shade", "k_us_bounce", "k_us_shade", "k_us_first", "k_film_accum", "k_film_resolve", "k_scale"):
         if k in n:
             return n[n.index(k):][:60]
     return n[:60]

@@ -25,10 +25,14 @@ b = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(b):
     shutil.copy(b, os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
 kernel = "k_us_bounce" if config.startswith("us_") else "k_bounce"
-# BVH scenes: a bounce is k_trace + k_shade (kernels_wavefront.h)
-families = (kernel, kernel + "_pool") if config != "testring" else ("k_trace_primary", "k_trace", "k_shade")
+# BVH scenes: a bounce is k_trace + k_shade (kernels_wavefront.h), k_trace + k_us_shade in ultrasound mode (kernels_us_wavefront.h)
+families = (kernel, kernel + "_pool")
 if config == "testring":
+    families = ("k_trace_primary", "k_trace", "k_shade")
     kernel = "k_trace_primary + k_trace + k_shade"
+if config == "us_testring":
+    families = ("k_trace", "k_us_shade")
+    kernel = "k_trace + k_us_shade"
 
 
 def per_dispatch(sub, ctr):
@@ -83,7 +87,7 @@ try:
         steps_pmc = 2.0
         fam_bytes = {}
         for k in fetch:
-            fam = "k_shade" if k.startswith("k_shade") else "k_trace_primary + k_trace"
+            fam = "k_shade" if k.startswith(("k_shade", "k_us_shade")) else "k_trace_primary + k_trace"
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + (fetch_factor * fetch[k] + write_factor * write.get(k, 0.0)) * 1024 * nf[k] / steps_pmc
         by_kernel = {fam: {"hbm_bytes_per_step": round(v), "algorithmic_bytes_per_step": alg[fam], "ratio": round(v / alg[fam], 3)}
                      for fam, v in fam_bytes.items() if alg.get(fam)}

@@ -304,7 +304,7 @@ int pbrt_get_stats(pbrt_ctx *ctx, pbrt_stats *out);
  * or PBRT_WORKSPACE_LIMIT_BYTES in the environment at pbrt_ctx_create; 0 = none -- and hands memory back with pbrt_ctx_trim.
  * Under a limit, and when an allocation fails, renders take smaller passes (same film, more passes); a request that cannot be met
  * at the smallest pass returns PBRT_E_NOMEM.  pbrt_film_desc.pass_paths still overrides the choice per call. */
-int pbrt_ctx_set_workspace_limit(pbrt_ctx *ctx, uint64_t bytes);
+int pbrt_ctx_set_workspace_limit(pbrt_ctx *ctx, uint64_t bytes); /* a limit below what the context holds frees its buffers at once */
 /* frees every workspace buffer the most recent call did not use and every one larger than that call needed; *held_after
  * (may be NULL) = bytes still held */
 int pbrt_ctx_trim(pbrt_ctx *ctx, uint64_t *held_after);

@@ -78,6 +78,16 @@ struct pbrt_ctx {
         // small buffers get 12.5 % of slack (a slightly larger request re-uses them); the large ones -- path state, ray and
         // radiance records, sized by the pass -- are allocated as asked
         const size_t want = bytes < (size_t(64) << 20) ? bytes + bytes / 8 + 256 : bytes + 256;
+        if (ws_limit && ws_total() + want > ws_limit) {  // make room: what this call has not asked for goes first
+            for (auto it = ws.begin(); it != ws.end();) {
+                if (it->second.stamp != call_seq && &it->second != &b) {
+                    if (it->second.p) (void)hipFree(it->second.p);
+                    it = ws.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
         if (ws_limit && ws_total() + want > ws_limit) {
             fail(PBRT_E_NOMEM, "workspace limit: %s wants %zu bytes on top of %zu held, limit %zu", name, want, ws_total(), ws_limit);
             return nullptr;
@@ -311,6 +321,14 @@ const char *pbrt_last_error(pbrt_ctx *c) { return c ? c->err.c_str() : g_ctxless
 int pbrt_ctx_set_workspace_limit(pbrt_ctx *c, uint64_t bytes) {
     if (!c) return PBRT_E_INVALID;
     c->ws_limit = (size_t)bytes;
+    if (bytes && c->ws_total() > bytes) {  // a limit below what the context holds: everything goes back (calls are synchronous, nothing is in use)
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (auto &kv : c->ws)
+            if (kv.second.p) (void)hipFree(kv.second.p);
+        c->ws.clear();
+        c->stats.workspace_bytes = 0;
+    }
     return PBRT_OK;
 }
 
@@ -1023,7 +1041,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // 183 GB of the 288 GB of an MI355X -- a renderer that owns the device takes it; one that shares it sets a limit, see
     // pbrt_ctx_set_workspace_limit, and pbrt_ctx_trim hands the memory back).  The free-memory figure is a snapshot
     // (another process may allocate between the query and the hipMalloc), so a failed allocation halves the pass and tries again.
-    ++c->call_seq;
+    // (pbrt_ctx::call_seq was bumped by the entry point, before its first workspace request.)
     const uint64_t WF_MIN_PASS = 1u << 20;
     uint64_t pass_paths = f->pass_paths ? f->pass_paths : (brute_scene ? (64u << 20) : (16u << 20));
     if (!f->pass_paths && wf_scene) {
@@ -1418,6 +1436,7 @@ extern "C" {
 
 int pbrt_render_radiance_dev(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
     if (!s) return PBRT_E_INVALID;
+    ++s->ctx->call_seq;
     return render_impl(s, cam, f, d_out);
 }
 
@@ -1426,6 +1445,7 @@ int pbrt_render_radiance(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_
     pbrt_ctx *c = s->ctx;
     NEED(c, cam && f && out);
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->call_seq;
     const size_t n = (size_t)f->crop_w * f->crop_h * ((f->flags & PBRT_FILM_RAW_ACCUM) ? 4 : 3);
     void *d = c->buf("film_out", n * 4);
     if (!d) return PBRT_E_NOMEM;
@@ -1703,7 +1723,6 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
-    ++c->call_seq;
     const uint32_t NA = p->n_angles, NE = p->n_elements, T = p->time_samples;
     const uint32_t n_rays = NA * NE;
     std::vector<float> tx(n_rays), dir0(3 * NA), ex(NE);
@@ -1943,6 +1962,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
 int pbrt_us_acquire_dev(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
                         uint32_t norm_paths, void *d_channel, float *tx) {
     if (!s) return PBRT_E_INVALID;
+    ++s->ctx->call_seq;
     return us_impl(s, p, seed, ppr, path_offset, norm_paths, (float *)d_channel, tx);
 }
 
@@ -1952,6 +1972,7 @@ int pbrt_us_acquire(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint3
     pbrt_ctx *c = s->ctx;
     NEED(c, p && channel);
     HIPCHK(c, hipSetDevice(c->device));
+    ++c->call_seq;
     const size_t n = (size_t)p->n_angles * p->n_elements * p->time_samples;
     void *d = c->buf("us_channel", n * 4);
     if (!d) return PBRT_E_NOMEM;

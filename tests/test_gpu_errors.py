@@ -83,7 +83,9 @@ def test_scenes_and_contexts_release_their_device_memory(mi):
 
     from conftest import scene_path
 
-    hip = ctypes.CDLL("libamdhip64.so")        # already loaded by libpbrt_hip.so: the same runtime instance
+    mi.default_context()                       # maps the library and, with it, the one HIP runtime of this process
+    path = next(ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64.so" in ln)
+    hip = ctypes.CDLL(path)                    # the copy that is already mapped (torch's bundled one or the system's): the same instance
 
     def free_bytes():
         free, total = ctypes.c_size_t(), ctypes.c_size_t()
@@ -114,12 +116,15 @@ def test_workspace_limit_and_trim(mi):
     ctx = mi.default_context()
     sc = mi.load_file(scene_path("testring.xml"), res=256, spp=64)
     try:
+        ctx.set_workspace_limit(1)      # below whatever earlier tests left behind: everything goes back, the test starts from nothing
+        assert ctx.trim() == 0
         ctx.set_workspace_limit(0)
         free = mi.render(sc, seed=3)
         st_free = ctx.stats()
-        assert st_free["passes"] == 1 and st_free["workspace_bytes"] > 1_400_000_000      # 4 Mi paths x 356 B
-        ctx.set_workspace_limit(600 << 20)
-        assert ctx.trim() < 600 << 20                                                      # the 1.5 GB of the free render go back
+        assert st_free["passes"] == 1 and st_free["workspace_bytes"] > 1_400_000_000      # 4 Mi paths x 340 B
+        assert 1_400_000_000 < ctx.trim() <= st_free["workspace_bytes"]                    # the pass buffers fit the last call: they stay
+        ctx.set_workspace_limit(600 << 20)                                                 # a limit below what is held: the 1.4 GB go back at once
+        assert ctx.trim() == 0
         capped = mi.render(sc, seed=3)
         st = ctx.stats()
         assert st["passes"] == 4 and st["pass_paths"] == 256 * 256 * 16
@@ -128,6 +133,16 @@ def test_workspace_limit_and_trim(mi):
         # a brute-force scene and an acquisition under the same limit
         cb = mi.load_file(scene_path("cbox.xml"), res=64, spp=8)
         assert np.isfinite(mi.render(cb, seed=1)).all() and ctx.stats()["workspace_bytes"] <= 600 << 20
+        # an acquisition on a mesh phantom (k_trace + k_us_shade share the radiance streams' workspace): three passes of 1 Mi paths
+        # under the limit, one without it -- the same echoes (f32 sums in another order)
+        us = mi.load_file(scene_path("us_testring.xml"))
+        ui = us.integrator()
+        few = ui._acquire(us, ui.quirks, paths_per_ray=8192, seed=2)
+        assert ctx.stats()["passes"] >= 3 and ctx.stats()["workspace_bytes"] <= 600 << 20
+        ctx.set_workspace_limit(0)
+        one = ui._acquire(us, ui.quirks, paths_per_ray=8192, seed=2)
+        assert ctx.stats()["passes"] == 1
+        assert np.array_equal(few != 0, one != 0) and np.allclose(few, one, rtol=2e-5, atol=1e-7 * np.abs(one).max())
         ctx.set_workspace_limit(50 << 20)
         ctx.trim()
         with pytest.raises(RuntimeError, match="workspace limit"):

@@ -121,6 +121,7 @@ struct RadArgs {
     uint32_t n_paths;  // paths generated by the first bounce of this pass
     uint32_t depth, max_depth, rr_depth, seed;
     uint32_t nb;  // bounces this launch walks (the multi-bounce variants k_bounce<.., 2>; 2 .. MAX_CHAIN)
+    uint32_t repack_mask;  // chain launches: bit b = after the launch's b-th bounce the workgroup packs its live paths to its first lanes (k_bounce)
     uint32_t merge_at;  // k_chain_pair: the bounce from which a wave walks the survivors of its two tiles together (1 .. max_depth - 1)
     // key mode 0 (render): home -> (region pixel, local sample)
     uint32_t key_mode;
@@ -428,6 +429,20 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     // multi-bounce launches: paths that went on to the launch's 2nd .. 6th bounce, 10 bits each (a workgroup has <= 512):
     // bounces 2 - 4 in wave_mid, 5 - 6 in wave_mid_hi
     __shared__ uint32_t wave_mid[2][NB > 1 ? SEG / 64 : 1], wave_mid_hi[2][NB > 1 ? SEG / 64 : 1];
+    // Repack inside a chain launch (round 4, build switch -DPBRT_CHAIN_REPACK: measured, lost): in the Cornell
+    // box 100 / 87 / 67 / 56 / 47 / 9 % of the lanes carry a path at bounces 0 .. 5.  After the bounces the host names
+    // (a.repack_mask, PBRT_CHAIN_REPACK=mask in the environment) the workgroup packs its live paths to its first lanes through LDS
+    // -- 15 dwords each, [row][thread] so that both sides are conflict-free -- and the waves left without a path retire (s_endpgm;
+    // the barriers do not wait for them).  Same paths, same arithmetic, other lanes: the film does not change.  What it gives is
+    // 2 % (a wave with few live lanes skips most of a bounce anyway); what its code costs the kernel at the 64-register budget is
+    // 8 % (20 spilled VGPRs, 30 KB of LDS per workgroup): 6.33 -> 6.84 ms with the switch compiled in and no bounce named, 6.69 at best.
+#ifdef PBRT_CHAIN_REPACK
+    constexpr bool REPACK = NB > 1 && ACCEL == ACCEL_K_BRUTE;
+#else
+    constexpr bool REPACK = false;
+#endif
+    __shared__ uint32_t rp_cnt[REPACK ? SEG / 64 : 1];
+    __shared__ float rp_state[REPACK ? N_STATE : 1][REPACK ? SEG : 1];
 
     const uint32_t seg = xcd_swizzle(blockIdx.x, gridDim.x);  // region index
     const uint32_t tid = threadIdx.x;
@@ -591,6 +606,70 @@ __global__ __launch_bounds__(seg_threads(ACCEL), NB > 1 ? (ACCEL == ACCEL_K_BRUT
     live = survive;
     nseg_w += (uint32_t)__popcll(__ballot(did_seg));
     nshd_w += (uint32_t)__popcll(__ballot(did_shadow));
+    if (REPACK && ((a.repack_mask >> bounce) & 1u) && bounce + 1 < nb_run && depth + 1 < a.max_depth) {  // uniform
+        const uint32_t wid_r = tid >> 6;
+        const unsigned long long bl = __ballot(live);
+        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(bl >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bl, 0u));
+        if ((tid & 63u) == 0) rp_cnt[wid_r] = (uint32_t)__popcll(bl);
+        __syncthreads();
+        const uint32_t c_lane = rp_cnt[tid & (SEG / 64 - 1)];
+        const uint32_t wid_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wid_r);
+        uint32_t off_r = 0, total_r = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < SEG / 64; ++w) {
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readlane((int)c_lane, (int)w);
+            off_r += (w < wid_s) ? t : 0u;
+            total_r += t;
+        }
+        if (live) {
+            const uint32_t k = off_r + pre;
+            rp_state[0][k] = o.x;
+            rp_state[1][k] = o.y;
+            rp_state[2][k] = o.z;
+            rp_state[3][k] = d.x;
+            rp_state[4][k] = d.y;
+            rp_state[5][k] = d.z;
+            rp_state[6][k] = thr.x;
+            rp_state[7][k] = thr.y;
+            rp_state[8][k] = thr.z;
+            rp_state[9][k] = L.x;
+            rp_state[10][k] = L.y;
+            rp_state[11][k] = L.z;
+            rp_state[12][k] = eta;
+            rp_state[13][k] = prev_pdf;
+            rp_state[14][k] = __uint_as_float(home);
+        }
+        __syncthreads();
+        live = tid < total_r;
+        if (live) {
+            o = {rp_state[0][tid], rp_state[1][tid], rp_state[2][tid]};
+            d = {rp_state[3][tid], rp_state[4][tid], rp_state[5][tid]};
+            thr = {rp_state[6][tid], rp_state[7][tid], rp_state[8][tid]};
+            L = {rp_state[9][tid], rp_state[10][tid], rp_state[11][tid]};
+            eta = rp_state[12][tid];
+            prev_pdf = rp_state[13][tid];
+            home = __float_as_uint(rp_state[14][tid]);
+            path_key<TILED>(a, home, &ka, &kb, &px, &py);
+        }
+        // a wave left without a path retires: it publishes what the end of the kernel expects from it (its counts of this launch,
+        // no survivors) and ends; the waves that go on never wait for it.  (The next repack must see it with no live lane: rp_cnt.)
+        // s_endpgm behind the compiler's back keeps the kernel single-exit for the structurizer (as the early exit above).
+        const uint32_t wave_first_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)tid) & ~63u;
+        if ((tid & 63u) == 0 && wave_first_r >= total_r && wave_first_r != 0u) {  // (wave 0 stays: thread 0 writes the region's counters)
+            rp_cnt[wid_r] = 0;
+            wave_tot[buf][wid_r] = 0;
+            wave_seg[buf][wid_r] = nseg_w;
+            wave_shd[buf][wid_r] = nshd_w;
+            wave_mid[buf][wid_r] = nmid_w;
+            wave_mid_hi[buf][wid_r] = nmid_hi_w;
+        }
+        const uint32_t keep = (uint32_t)__builtin_amdgcn_readfirstlane((int)((wave_first_r < total_r || wave_first_r == 0u) ? 1u : 0u));
+        asm volatile("s_cmp_lg_u32 %0, 0\n\t"
+                     "s_cbranch_scc1 .Lstay_%=\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "s_endpgm\n"
+                     ".Lstay_%=:" ::"s"(keep) : "scc", "memory");
+    }
     }  // bounces of this launch
     // ---- segment-local stream compaction: ballot + mbcnt inside the wave, LDS scan across waves
     const uint32_t wid = tid >> 6;

@@ -532,6 +532,12 @@ static void launch_walk(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t
     }
 }
 #endif
+// In-kernel repack of a chain launch (kernels_radiance.h k_bounce, REPACK): after which of its bounces the workgroup packs its live
+// paths together.  PBRT_CHAIN_REPACK=mask overrides (0: never).
+static uint32_t chain_repack_mask() {
+    static const char *e = getenv("PBRT_CHAIN_REPACK");
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+}
 // nb: bounces this launch walks (>= 2: the multi-bounce variants of the brute-force kernels, kernels_radiance.h; a.nb = nb)
 template <bool FIRST>
 static int launch_bounce(pbrt_scene *s, const RadArgs &a, uint32_t nseg, uint32_t nb = 1) {
@@ -1241,6 +1247,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
             const uint32_t nb = brute ? chain_len(fuse_plan, depth, f->max_depth) : 1u;
             a.depth = depth;
             a.nb = nb;
+            a.repack_mask = chain_repack_mask();
             a.in = in;
             a.out = out;
             a.seg_in = sin;

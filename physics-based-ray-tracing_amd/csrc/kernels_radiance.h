@@ -1306,7 +1306,10 @@ __global__ __launch_bounds__(FILM_TILE *FILM_TILE) void k_film_accum_tiled(const
     const float4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     // radiance records of the next PF samples, requested PF iterations ahead: one iteration is shorter than an HBM / L2
     // round trip (with a distance of one the loop ran at 2.3 us per sample whatever the workgroup count)
-    constexpr int PF = 4;
+#ifndef FILM_PF
+#define FILM_PF 4
+#endif
+    constexpr int PF = FILM_PF;
     float4 Lq[PF][NST];
 #pragma unroll
     for (int u = 0; u < PF; ++u)

@@ -45,8 +45,8 @@
 #define WF_SHADE_THREADS 256u
 #endif
 #ifndef WF_SHADE_WAVES_PER_EU
-#define WF_SHADE_WAVES_PER_EU 5
-#endif
+#define WF_SHADE_WAVES_PER_EU 4   // 128 VGPRs, nothing spilled (round 4, ring 1024^2 x 256: 5 / 4 / 3 waves -> 49.3 / 47.1 / 47.4 ms; at 5 the
+#endif                            // 12 spilled registers of k_shade<false> were scratch traffic of a kernel that waits on HBM)
 // a wave whose walkers fall below WF_WALK_MIN stops walking to fetch rays: its idle lanes must then reach WF_REFILL_MIN (64 -
 // walkers, when no lane holds a leaf), or it would neither walk nor fetch (the turn guard caught exactly that with 48 / 32)
 static_assert(WF_REFILL_MIN + WF_WALK_MIN <= 65u, "k_trace: a wave below WF_WALK_MIN walkers must be able to refill");

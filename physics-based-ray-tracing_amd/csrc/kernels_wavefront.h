@@ -44,6 +44,9 @@
 #ifndef WF_SHADE_THREADS
 #define WF_SHADE_THREADS 256u
 #endif
+#ifndef WF_SHADE_CHUNKS
+#define WF_SHADE_CHUNKS 2      // 64-slot chunks of hit indices (+ 48 B of state each at bounces >= 1) a wave of k_shade requests per step: twice the
+#endif                         // bytes in flight where the kernel had fewest (round 4, ring 1024^2 x 256: 1 / 2 / 3 -> 49.0 / 46.9 / 47.8 ms)
 #ifndef WF_SHADE_WAVES_PER_EU
 #define WF_SHADE_WAVES_PER_EU 4   // 128 VGPRs, nothing spilled (round 4, ring 1024^2 x 256: 5 / 4 / 3 waves -> 49.3 / 47.1 / 47.4 ms; at 5 the
 #endif                            // 12 spilled registers of k_shade<false> were scratch traffic of a kernel that waits on HBM)
@@ -566,8 +569,9 @@ DEV Tables wf_tables_lds(const DevScene &sc, uint32_t *lds, uint32_t n_threads) 
 template <bool FIRST, bool TABS>
 __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_shade(const WfArgs a) {
     constexpr uint32_t T = WF_SHADE_THREADS, W = T / 64;
-    // per wave: the paths that hit something and wait for a full wave -- slot within the region, and the hit record
-    __shared__ uint32_t wlist[W][128], wprim[W][128];
+    constexpr int NCH = WF_SHADE_CHUNKS;  // chunks of 64 hit indices a wave reads per step
+    // per wave: the paths that hit something and wait for a full wave -- slot within the region, and the primitive that was hit
+    __shared__ uint32_t wlist[W][64 * (NCH + 1)], wprim[W][64 * (NCH + 1)];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
     const uint32_t r = a.region0 + xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
@@ -608,47 +612,60 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
     uint32_t c0 = wid * 64u;         // the wave's next chunk of the region
     for (;;) {
         if (c0 < cnt_in) {
-            // ---- a chunk of hit records: paths whose ray left the scene end here, the others go on the list.  One batch of
-            // loads: the hit record and (bounces >= 1) the four state planes a path that ends needs.
-            const uint32_t s = c0 + lane;
-            const bool valid = s < cnt_in;
-            uint32_t hid = 0xffffffffu;
-            float4 q3 = {0, 0, 0, 0}, q4 = {0, 0, 0, 0}, q5 = {0, 0, 0, 0};
-            if (valid) {
-                hid = a.hit_id[base + s];
-                if (!FIRST) {
-                    const float4 *stp = a.st_in + (base + s);
-                    const size_t cp = a.cap;
-                    q3 = stp[3u * cp];
-                    q4 = stp[4u * cp];
-                    q5 = stp[5u * cp];
+            // ---- WF_SHADE_CHUNKS chunks of hit records: paths whose ray left the scene end here, the others go on the list.  One
+            // batch of loads: the hit indices and (bounces >= 1) the three state planes a path that ends needs.
+            uint32_t hidv[NCH];
+            float4 q3v[NCH], q4v[NCH], q5v[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const uint32_t s = c0 + (uint32_t)j * (W * 64u) + lane;
+                hidv[j] = 0xffffffffu;
+                q3v[j] = q4v[j] = q5v[j] = float4{0, 0, 0, 0};
+                if (s < cnt_in) {
+                    hidv[j] = a.hit_id[base + s];
+                    if (!FIRST) {
+                        const float4 *stp = a.st_in + (base + s);
+                        const size_t cp = a.cap;
+                        q3v[j] = stp[3u * cp];
+                        q4v[j] = stp[4u * cp];
+                        q5v[j] = stp[5u * cp];
+                    }
                 }
             }
-            const bool is_hit = hid != 0xffffffffu;
-            if (valid && !is_hit) {
-                float4 Lv = q3;
-                if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
-                    Lv.x = fma_(q4.x, q5.x, Lv.x);
-                    Lv.y = fma_(q4.y, q5.y, Lv.y);
-                    Lv.z = fma_(q4.z, q5.z, Lv.z);
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const uint32_t s = c0 + (uint32_t)j * (W * 64u) + lane;
+                const bool valid = s < cnt_in;
+                const uint32_t hid = hidv[j];
+                const float4 q3 = q3v[j], q4 = q4v[j], q5 = q5v[j];
+                const bool is_hit = hid != 0xffffffffu;
+                if (valid && !is_hit) {
+                    float4 Lv = q3;
+                    if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
+                        Lv.x = fma_(q4.x, q5.x, Lv.x);
+                        Lv.y = fma_(q4.y, q5.y, Lv.y);
+                        Lv.z = fma_(q4.z, q5.z, Lv.z);
+                    }
+                    Lv.w = 0.0f;
+                    Lh[FIRST ? base + s : __float_as_uint(q3.w)] = Lv;
                 }
-                Lv.w = 0.0f;
-                Lh[FIRST ? base + s : __float_as_uint(q3.w)] = Lv;
-            }
-            const unsigned long long bh = __ballot(is_hit);
-            if (is_hit) {
-                const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
-                wlist[wid][e] = s;
-                wprim[wid][e] = hid;
+                const unsigned long long bh = __ballot(is_hit);
+                if (is_hit) {
+                    const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
+                    wlist[wid][e] = s;
+                    wprim[wid][e] = hid;
+                }
+                list_n += (uint32_t)__popcll(bh);
             }
             __builtin_amdgcn_wave_barrier();  // other lanes of the wave read these entries below (LDS operations of a wave stay in order)
-            list_n += (uint32_t)__popcll(bh);
-            c0 += W * 64u;
+            c0 += (uint32_t)NCH * W * 64u;
         } else if (list_n == 0) {
             break;
         }
         if (list_n < 64u && c0 < cnt_in) continue;
-        // ---- shade 64 listed paths (or what is left at the end) with every lane busy
+        // ---- shade 64 listed paths (or what is left at the end) with every lane busy; the list is emptied below 64 entries before
+        // the wave reads its next chunks (the list holds 64 x (WF_SHADE_CHUNKS + 1))
+        for (;;) {
         const uint32_t take = min(list_n, 64u);
         const bool act = lane < take;
         list_n -= take;
@@ -758,6 +775,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 rec[3u * cp] = q3;
             }
         }
+        if (list_n < 64u && c0 < cnt_in) break;  // room for the next chunks
+        if (list_n == 0u) break;
+        }  // shading steps
     }
     if (lane == 0) {
         unsigned long long *row = a.stats + (size_t)r * W + wid;  // per-wave statistics rows

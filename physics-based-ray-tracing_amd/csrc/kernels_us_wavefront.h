@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256) void k_us_init_wf(const UsArgs a, float4 *st, 
 template <bool TAB>
 __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_shade(const UsWfArgs w) {
     constexpr uint32_t T_ = WF_SHADE_THREADS, W = T_ / 64;
+    constexpr int NCH = WF_SHADE_CHUNKS;
     const UsArgs &a = w.u;
-    __shared__ uint32_t wlist[W][128], wprim[W][128];
+    __shared__ uint32_t wlist[W][64 * (NCH + 1)], wprim[W][64 * (NCH + 1)];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t agg_idx[US_AGG_BINS];
     __shared__ float agg_sum[US_AGG_BINS];
@@ -112,35 +113,49 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
     uint32_t c0 = wid * 64u;
     for (;;) {
         if (c0 < cnt_in) {
-            const uint32_t s = c0 + lane;
-            const bool valid = s < cnt_in;
-            uint32_t hid = 0xffffffffu;
-            if (valid) {
-                if (TAB) {
-                    const uint32_t ray_id = udiv_fast(base + s, a.div_ppr);
-                    hid = __float_as_uint(a.first_hit[ray_id].w);  // the primitive the ray's shared first hit lies on
-                } else {
-                    hid = w.hit_id[base + s];
-                    // the pending echo of the previous bounce (every path, whether it goes on or not)
-                    const float4 q2 = w.st_in[2u * cp + base + s], q3 = w.st_in[3u * cp + base + s];
-                    if (q3.w != 0.0f && __float_as_uint(q2.w) != 0xffffffffu) deposit(__float_as_uint(q2.w), q3.x);
+            // WF_SHADE_CHUNKS chunks per step, their loads in one batch (kernels_wavefront.h k_shade)
+            uint32_t hidv[NCH];
+            float4 q2v[NCH], q3v[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const uint32_t s = c0 + (uint32_t)j * (W * 64u) + lane;
+                hidv[j] = 0xffffffffu;
+                q2v[j] = q3v[j] = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (s < cnt_in) {
+                    if (TAB) {
+                        const uint32_t ray_id = udiv_fast(base + s, a.div_ppr);
+                        hidv[j] = __float_as_uint(a.first_hit[ray_id].w);  // the primitive the ray's shared first hit lies on
+                    } else {
+                        hidv[j] = w.hit_id[base + s];
+                        q2v[j] = w.st_in[2u * cp + base + s];
+                        q3v[j] = w.st_in[3u * cp + base + s];
+                    }
                 }
             }
-            const bool is_hit = hid != 0xffffffffu;
-            const unsigned long long bh = __ballot(is_hit);
-            if (is_hit) {
-                const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
-                wlist[wid][e] = s;
-                wprim[wid][e] = hid;
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const uint32_t s = c0 + (uint32_t)j * (W * 64u) + lane;
+                const uint32_t hid = hidv[j];
+                // the pending echo of the previous bounce (every path, whether it goes on or not)
+                if (!TAB && s < cnt_in && q3v[j].w != 0.0f && __float_as_uint(q2v[j].w) != 0xffffffffu) deposit(__float_as_uint(q2v[j].w), q3v[j].x);
+                const bool is_hit = hid != 0xffffffffu;
+                const unsigned long long bh = __ballot(is_hit);
+                if (is_hit) {
+                    const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
+                    wlist[wid][e] = s;
+                    wprim[wid][e] = hid;
+                }
+                list_n += (uint32_t)__popcll(bh);
             }
             __builtin_amdgcn_wave_barrier();
-            list_n += (uint32_t)__popcll(bh);
-            c0 += W * 64u;
+            c0 += (uint32_t)NCH * W * 64u;
         } else if (list_n == 0) {
             break;
         }
         if (list_n < 64u && c0 < cnt_in) continue;
-        // ---- shade 64 listed paths: kernels_us.h k_us_bounce from the hit on, statement for statement
+        // ---- shade 64 listed paths: kernels_us.h k_us_bounce from the hit on, statement for statement (the list is emptied below 64
+        // entries before the wave reads its next chunks)
+        for (;;) {
         const uint32_t take = min(list_n, 64u);
         const bool act = lane < take;
         list_n -= take;
@@ -318,6 +333,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
                 w.shd_out[2u * cp + k] = q2;
             }
         }
+        if (list_n < 64u && c0 < cnt_in) break;  // room for the next chunks
+        if (list_n == 0u) break;
+        }  // shading steps
     }
     if (lane == 0) {
         unsigned long long *row = a.stats + (size_t)r * W + wid;  // per-wave statistics rows

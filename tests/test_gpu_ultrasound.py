@@ -288,3 +288,34 @@ def test_mesh_phantoms_as_streams_and_as_the_fused_bounce(mi, ob, capi, scene, k
         os.environ.pop("PBRT_US_FUSED_BVH", None)
     check(fused, ref)
     assert st_f["bounce_launches"] == 1 and st_f["segments"] == st["segments"] and list(st_f["live"]) == list(st["live"])
+
+
+@pytest.mark.parametrize("case", ["intent", "drjit", "depth1", "depth2_no_tables", "pulse"])
+def test_mesh_phantom_variants_of_the_acquisition_loop(mi, ob, capi, case):
+    """the stream kernels (k_trace + k_us_shade) under the switches of the acquisition loop, on the ring phantom, against the oracle:
+    intent arithmetic (quirks = 0), the Dr.Jit variant (frozen draws, clamped bins, no tof accumulation, signed roulette),
+    max_depth 1 (every path ends at its first bounce: with fewer paths per ray than elements there are no tables, so every echo waits
+    for its occlusion ray in a record of an ended path and is deposited by the flush), max_depth 2 without tables (pending echoes of
+    survivors and of ended paths together), and echoes without the carrier (pulse model)."""
+    ppr = {"depth1": 24, "depth2_no_tables": 80}.get(case, 96)
+    sc = mi.load_file(scene_path("us_testring.xml"), paths_per_ray=ppr, seed=21)
+    ui = sc.integrator()
+    q = ui.quirks
+    if case == "intent":
+        q = 0
+    elif case == "drjit":
+        q |= capi.USQ_DRJIT_VARIANT
+    elif case == "depth1":
+        ui.max_depth = 1
+    elif case == "depth2_no_tables":
+        ui.max_depth = 2
+        q |= capi.USQ_NO_FIRST_TABLES
+    elif case == "pulse":
+        q |= capi.USQ_NO_CARRIER
+    buf = ui._acquire(sc, q, pulse=False)
+    st = mi.default_context().stats()
+    ref, _ = ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc, q), 21, ppr)
+    check(buf, ref)
+    assert (buf != 0).sum() > 500
+    if case == "depth1":
+        assert st["live"][1] == 0 and st["bounce_launches"] == 2 + 2     # trace + shade of bounce 0 (the rays come from k_us_init_wf), then the flush

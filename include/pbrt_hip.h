@@ -152,7 +152,7 @@ typedef struct pbrt_film_desc {
     uint32_t seed;
     uint32_t flags;      /* PBRT_FILM_*                                                  */
     uint32_t pass_paths; /* 0 = library default; paths kept in flight per pass.  Default: 64 Mi for brute-force scenes
-                            (8 B..120 B of workspace per path, by launch plan); BVH scenes (356 B per path) the largest power of
+                            (8 B..120 B of workspace per path, by launch plan); BVH scenes (340 B per path) the largest power of
                             two, 1 .. 512 Mi, whose workspace fits two thirds of the free device memory -- pbrt_stats reports both */
 } pbrt_film_desc;
 

@@ -1039,7 +1039,7 @@ static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_de
     // 6.72 / 6.56 / 6.49 / 6.43 ms
     // round 3, BVH scenes as trace / shade streams (twelve launches per pass: their tails and the thinly filled late bounces weigh
     // less in larger passes): ring 1024^2 x 64: 1 / 2 / 4 / 8 / 16 / 32 / 64 Mi -> 50.8 / 37.6 / 25.5 / 22.2 / 19.6 / 18.0 / 17.3 ms;
-    // 64 Mi paths = 23 GB of workspace (356 B per path in flight); the fused BVH kernels (PBRT_FILM_NO_HIT_POOL) keep 16 Mi
+    // 64 Mi paths = 23 GB of workspace (356 B per path in flight then, 340 B since round 4); the fused BVH kernels (PBRT_FILM_NO_HIT_POOL) keep 16 Mi
     const bool wf_scene = !brute_scene && !(f->flags & PBRT_FILM_NO_HIT_POOL);
     // and beyond: 1024^2 x 512: 64 / 128 / 256 Mi -> 144 / 134 / 115 ms.  Default for BVH scenes: the largest power of two whose
     // workspace (WF_BYTES_PER_PATH = 340 B per path in flight, allocated as asked) fits two thirds of the free device memory and

@@ -374,8 +374,9 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                                        "only HBM traffic left is one 16-byte radiance record per path (hbm_* keys)")
         if name in ("testring", "us_testring"):
             # per step, so that the PMC bytes of the two kernel families (profiles/pmc_traffic.json) have their own denominators
-            out["roofline"]["algorithmic_bytes_per_step"] = {"k_trace_primary + k_trace": round(acc["trace_bytes"] / steps),
-                                                             "k_shade": round((acc["bounce_bytes"] - acc["trace_bytes"]) / steps)}
+            walk, shade = ("k_trace_primary + k_trace", "k_shade") if radiance else ("k_trace", "k_us_shade")
+            out["roofline"]["algorithmic_bytes_per_step"] = {walk: round(acc["trace_bytes"] / steps),
+                                                             shade: round((acc["bounce_bytes"] - acc["trace_bytes"]) / steps)}
         if radiance and name == "testring":
             out["roofline"]["note"] = ("a bounce is two launches: k_trace (stream of closest-hit and shadow queries against the LDS-resident BVH4, "
                                        "8 waves per SIMD; the camera rays: k_trace_primary, one tree walk per 64-path tile) and k_shade (full "

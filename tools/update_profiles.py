@@ -83,11 +83,14 @@ by_kernel = None
 try:
     bj = json.load(open(b))
     alg = bj["roofline"].get("algorithmic_bytes_per_step")
+    if alg and config.startswith("us_") and "k_us_shade" not in alg:   # records made before the ultrasound families had their names
+        alg = {"k_trace": alg["k_trace_primary + k_trace"], "k_us_shade": alg["k_shade"]}
     if alg:
         steps_pmc = 2.0
         fam_bytes = {}
         for k in fetch:
-            fam = "k_shade" if k.startswith(("k_shade", "k_us_shade")) else "k_trace_primary + k_trace"
+            walk, shade = ("k_trace", "k_us_shade") if config.startswith("us_") else ("k_trace_primary + k_trace", "k_shade")
+            fam = shade if k.startswith(("k_shade", "k_us_shade")) else walk
             fam_bytes[fam] = fam_bytes.get(fam, 0.0) + (fetch_factor * fetch[k] + write_factor * write.get(k, 0.0)) * 1024 * nf[k] / steps_pmc
         by_kernel = {fam: {"hbm_bytes_per_step": round(v), "algorithmic_bytes_per_step": alg[fam], "ratio": round(v / alg[fam], 3)}
                      for fam, v in fam_bytes.items() if alg.get(fam)}

@@ -78,7 +78,7 @@ CONFIGS = {
 def kernel_source_hash():
     """sha256 over the kernel sources and the build flags: ties profiles/pmc_traffic.json to the code it was measured on (the
     GPU box has no .git to ask for HEAD).  Comments and blank lines are left out, so a reworded comment does not orphan a
-    measurement."""
+    measurement.  Of the Makefile only the lines that set the compiler, the target and the flags count."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, PKG, "csrc")
     for name in sorted(os.listdir(d)):
@@ -86,6 +86,8 @@ def kernel_source_hash():
             h.update(name.encode())
             for line in open(os.path.join(d, name), "r", errors="replace"):
                 code = line.split("//", 1)[0].strip() if name != "Makefile" else line.split("#", 1)[0].strip()
+                if name == "Makefile" and not code.startswith(("HIPCC", "ARCH", "HIPFLAGS")):
+                    continue
                 if code:
                     h.update(code.encode())
                     h.update(b"\n")

@@ -50,8 +50,14 @@ inline bool cone_world_frame(const pbrt_prim &P, double c[3], double a[3], doubl
 // SAH parameters (A/B-able): cost of one node step relative to one primitive test, and the largest leaf.
 // Measured on MI355X (ring 1024^2 x 64 spp / 896-triangle cone phantom): 0.25 / 0.5 / 1 / 2 at <= 4 per leaf:
 // 21.95 / 22.05 / 22.10 / 24.13 ms; leaves of <= 2 / 6 / 8: 22.07 / 22.13 / 24.04 ms -- flat around the defaults.
+// Trees that stay in global memory (BVH_CTRAV_GLOBAL, round 4): a node step is a 64-byte gather per lane there, a primitive test a
+// 40-byte one -- 0.25 / 0.5 / 1 / 2: bunny.ply 23.5 / 22.4 / 21.3 / 21.9 ms, suzanne.ply 19.1 / 19.1 / 18.4 / 18.5 ms (1024^2 x 64),
+// while the ring phantom in LDS loses 3 % in ultrasound mode at 1 (profiles/r04_bunny_global_tree.txt).
 #ifndef BVH_CTRAV
 #define BVH_CTRAV 0.5f
+#endif
+#ifndef BVH_CTRAV_GLOBAL
+#define BVH_CTRAV_GLOBAL 1.0f
 #endif
 #ifndef BVH_MAX_LEAF
 #define BVH_MAX_LEAF 4
@@ -107,6 +113,7 @@ struct Builder {
     std::vector<float> cent;
     HostBvh *out;
     float pad;
+    float ctrav = BVH_CTRAV;
 
     // nodes[idx] must already exist
     void build(uint32_t idx, uint32_t first, uint32_t count, uint32_t depth) {
@@ -160,7 +167,7 @@ struct Builder {
             }
             for (int b = 0; b + 1 < NB; ++b) {
                 if (lc[b] == 0 || rc[b + 1] == 0) continue;
-                float cost = BVH_CTRAV * bb.area() + la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+                float cost = ctrav * bb.area() + la[b] * lc[b] + ra[b + 1] * rc[b + 1];
                 if (cost < best_cost) {
                     best_cost = cost;
                     best_axis = axis;
@@ -199,8 +206,9 @@ struct Builder {
 
 }  // namespace bvh_detail
 
-inline void build_bvh(const pbrt_prim *prims, uint32_t n, HostBvh *out) {
+inline void build_bvh(const pbrt_prim *prims, uint32_t n, HostBvh *out, float ctrav = BVH_CTRAV) {
     bvh_detail::Builder b;
+    b.ctrav = ctrav;
     b.prims = prims;
     b.out = out;
     b.boxes.resize(n);

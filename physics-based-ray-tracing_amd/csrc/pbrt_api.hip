@@ -442,7 +442,9 @@ int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
 #endif
     } else {
         HostBvh bvh;
-        build_bvh(d->prims, d->n_prims, &bvh);
+        // (a tree whose leaf records alone exceed the LDS stays in global memory whatever its shape: the SAH constant of those trees)
+        const bool sure_global = !c->lds_limit || (size_t)d->n_prims * sizeof(DevLeafPrim) > c->lds_limit || d->accel == PBRT_ACCEL_BVH_GLOBAL;
+        build_bvh(d->prims, d->n_prims, &bvh, sure_global ? BVH_CTRAV_GLOBAL : BVH_CTRAV);
         HostBvh4 b4;
         to_bvh4(bvh, &b4);
         // traversal stack: one entry per level of inner nodes, 24-bit node indices (device_scene.h BvhStack)

@@ -58,7 +58,8 @@ int main(int argc, char **argv) {
         prims.push_back(P);
     }
     const uint32_t n = (uint32_t)prims.size();
-    HostBvh b; build_bvh(prims.data(), n, &b);
+    // argv[3]: the SAH traversal cost (default: the constant of trees that fit the LDS; the library builds the others with BVH_CTRAV_GLOBAL)
+    HostBvh b; build_bvh(prims.data(), n, &b, argc > 3 ? (float)atof(argv[3]) : BVH_CTRAV);
     HostBvh4 b4; to_bvh4(b, &b4);
     std::vector<HostLeafPrim> lp; make_leaf_prims(prims.data(), b.order, &lp);
     // structural check: every leaf record's box lies inside the grid box of its slot in the parent, all the way up

@@ -21,9 +21,10 @@ def checker(tmp_path_factory):
     return exe
 
 
-def run(checker, tris, rows, rays=30000):
+def run(checker, tris, rows, rays=30000, ctrav=None):
     text = "\n".join(" ".join(repr(float(x)) for x in t.reshape(-1)) for t in tris)
-    p = subprocess.run([checker, str(rows), str(rays)], input=text, capture_output=True, text=True, timeout=300)
+    p = subprocess.run([checker, str(rows), str(rays)] + ([str(ctrav)] if ctrav is not None else []), input=text, capture_output=True,
+                       text=True, timeout=300)
     rep = json.loads(p.stdout.strip().splitlines()[-1])
     assert p.returncode == 0, rep
     return rep
@@ -52,3 +53,13 @@ def test_teapot_and_a_triangle_soup(mi, checker):
     soup[::50] *= 1e-3  # tiny triangles beside large ones: coarse grids at the top, fine ones below
     rep = run(checker, soup, 3)
     assert rep["outside_grid"] == 0 and rep["mismatches"] == 0 and rep["runaway"] == 0 and rep["max_sp"] <= rep["depth4"]
+
+
+def test_trees_of_the_global_memory_constant(mi, checker):
+    """meshes whose leaf records exceed the LDS are built with the SAH traversal cost 1.0 (bvh_build.h BVH_CTRAV_GLOBAL): a shallower
+    tree with fuller leaves, same closest hits; the stack still needs one entry per level at most"""
+    tris = mesh_tris(mi, "teapot.ply")
+    lds, glob = run(checker, tris, 3), run(checker, tris, 3, ctrav=1.0)
+    for rep in (lds, glob):
+        assert rep["outside_grid"] == 0 and rep["mismatches"] == 0 and rep["runaway"] == 0 and rep["max_sp"] <= rep["depth4"] <= 32
+    assert glob["nodes4"] <= lds["nodes4"]     # a dearer node step never buys more nodes

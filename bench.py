@@ -19,7 +19,9 @@ N > 1            BASELINE config 5: the same scene at 4096 x 4096, 1024 spp (17.
 
 With no --config at N = 1 the line also carries `also`: the other named scenes of BASELINE.json (us_sphere_box = config 3,
 testring = config 4, cbox4k = config 5 on one GPU), 3 steps each after the headline steps, each with its own roofline and its L2
-against the CPU port on a bounded sample; and `seeds`: the headline render at seeds 1 and 2.
+against the CPU port on a bounded sample; `seeds`: the headline render at seeds 1 and 2; and `scale_ref`: the
+N = 1 value of the workload `--gpus N > 1` runs (cbox4k), so that a scaling curve has its own one-GPU point on the line.  At N > 1
+the line carries `speedup_vs_scale_ref` when PBRT_SCALE_REF_MSAMPLES hands that value over.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     -- the dominant kernels (k_bounce / k_us_bounce / k_trace_primary + k_trace + k_shade), bound = "hbm" as the contract
@@ -94,16 +96,43 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT loading a GPU runtime: the KFD topology in sysfs (a node with
+    simd_count > 0 is a GPU; CPUs are nodes too), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when they are
+    set.  The launcher parent must stay a process that has never touched the GPU (its children are forked from it)."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in os.listdir(base):
+            try:
+                with open(os.path.join(base, node, "properties")) as f:
+                    for line in f:
+                        k, _, v = line.partition(" ")
+                        if k == "simd_count" and int(v) > 0:
+                            n += 1
+                            break
+            except (OSError, ValueError):
+                continue
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([t for t in v.split(",") if t.strip() != ""])
+            n = min(n, listed) if n else 0
+    return n
+
+
 def launch_ranks(args, argv):
-    """--gpus N > 1 outside torchrun: start the ranks as fresh children of a parent that has not initialised the GPU."""
+    """--gpus N > 1 outside torchrun: start the ranks as fresh children of a parent that has not initialised the GPU
+    (no torch import, no HIP call: the GPUs are counted in sysfs)."""
     # under rocprofv3 the profiler's preloaded library has initialised the GPU in THIS process already and the children would
     # inherit the preload: refuse (profile multi-rank runs rank by rank, `rocprofv3 ... -- python3 bench.py` under torchrun's env)
     if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ):
         print("bench.py: --gpus N > 1 would launch ranks from a profiled process; run one rank per rocprofv3 instead", file=sys.stderr)
         return 2
     if not args.rehearse_on_one_gpu:
-        import torch  # (device_count() does not initialise the GPU; the ranks are fresh child processes either way)
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if args.gpus > have:
             print(f"bench.py: --gpus {args.gpus} but this node shows {have} GPU(s); a multi-rank rehearsal on one GPU is "
                   f"--rehearse-on-one-gpu (gloo, not a benchmark)", file=sys.stderr)
@@ -116,6 +145,7 @@ def launch_ranks(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    assert "torch" not in sys.modules, "the launcher parent must not load torch (or any GPU runtime)"
     return subprocess.call(cmd, env=env)
 
 
@@ -190,12 +220,31 @@ def main():
             keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline", "l2_vs_cpu_ref", "cpu_baseline", "config")
                     if k in o}
             out["also"].append(keep)
+            if other == "cbox4k":
+                # the N = 1 point of the workload `--gpus N > 1` runs (BASELINE config 5): a 1 -> 8 curve must be read against
+                # THIS value, not against the headline (config 2, another workload)
+                out["scale_ref"] = {"config": "cbox4k", "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
+                                    "samples_per_step": o["config"]["samples_per_step"], "n_gpus": 1}
         out["seeds"] = {"0": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
         for sd in (1, 2):  # seeds 0, 1, 2
             o = measure(env, name, dict(cfg), 5, 1, seed=sd, overridden=False, with_cpu=False)
             out["seeds"][str(sd)] = {"value": o["value"], "ms_per_step": o["ms_per_step"]}
         if not args.no_cpu_baseline:
             out["seeds"]["parity"] = seed_parity(env, cfg)
+    if rank == 0 and name == "cbox4k":
+        if world == 1 and not overridden:
+            out["scale_ref"] = {"config": "cbox4k", "value": out["value"], "unit": out["unit"], "ms_per_step": out["ms_per_step"],
+                                "samples_per_step": out["config"]["samples_per_step"], "n_gpus": 1}
+        elif world > 1:
+            # the one-GPU value of the same workload, handed over by whoever ran it (the N = 1 line's scale_ref.value)
+            ref = os.environ.get("PBRT_SCALE_REF_MSAMPLES")
+            try:
+                ref = float(ref) if ref else None
+            except ValueError:
+                ref = None
+            out["scale_ref"] = {"config": "cbox4k", "value": ref, "unit": "Msamples/s", "n_gpus": 1,
+                                "source": "PBRT_SCALE_REF_MSAMPLES" if ref else "not given (set PBRT_SCALE_REF_MSAMPLES to the N = 1 line's scale_ref.value)"}
+            out["speedup_vs_scale_ref"] = round(out["value"] / ref, 4) if ref else None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force:

@@ -34,6 +34,7 @@ struct UsWfArgs {
     const uint32_t *seg_in, *nsh_in;
     uint32_t *seg_out, *nsh_out;
     uint32_t region0, n_regions;
+    uint32_t *guard;                // the context's guard words (kernels_wavefront.h WfArgs::guard)
 };
 
 // primary rays of a pass into the path state (depth 0 without first-bounce tables): CustomIntegrator.py:270-279
@@ -199,7 +200,11 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
             const bool has_vn = a.sc.vnormals != nullptr;  // uniform
             WfVn vn;
             if (has_vn) vn = wf_load_vn(a.sc.vnormals, h.slot);
-            if (!TAB) (void)prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v);  // (t, u, v) of the hit k_trace found: kernels_wavefront.h k_shade
+            if (!TAB) {  // (t, u, v) of the hit k_trace found; a repetition that disagrees fails the call (kernels_wavefront.h k_shade)
+                h.t = K_INF;
+                h.u = h.v = 0.0f;
+                if (!prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v)) atomicAdd(w.guard + WF_GUARD_REHIT, 1u);
+            }
             const uint32_t depth = a.depth;
             const V3 tn = {uni[12], uni[13], uni[14]};
             const SI si = wf_make_si(P, o, d, h.t, h.u, h.v, has_vn, vn);

@@ -76,7 +76,8 @@ struct WfArgs {
     uint32_t lds_bytes;          // ACCEL_K_BVH_LDS: bytes of the staged image
     uint32_t stk_rows, stk_shift;  // traversal stacks behind the image: rows, log2(threads of the workgroup)
     uint32_t vis_q;              // plane of the path state whose .w takes a shadow ray's visibility (radiance: 4, ultrasound: 3)
-    uint32_t *guard;             // WF_GUARD_WORDS words of the context: [0] waves that ran into the turn guard, [1..] state of one of them
+    uint32_t *guard;             // WF_GUARD_WORDS words of the context: [0] waves that ran into the turn guard, [1..30] state of one of them,
+                                 // [WF_GUARD_REHIT] hits whose (t, u, v) the shading kernels could not reproduce
 };
 
 DEV RadArgs wf_key_args(const WfArgs &a) {  // path_key reads these members only
@@ -110,6 +111,7 @@ DEV void wf_camera_ray(const WfArgs &a, uint32_t home, V3 *o, V3 *d, float *tmax
 // PBRT_E_DEVICE instead of hanging the box.  `turns` counts trips of the main loop and of the node walk; both loops are
 // wave-uniform, so it lives in a scalar register and every lane of the wave sees the trip.
 #define WF_GUARD_TURNS (1u << 22)
+#define WF_GUARD_REHIT 31u  // guard word: hits of k_trace that k_shade / k_us_shade could not reproduce (must stay 0)
 #ifdef PBRT_WF_PROBE  // diagnostic builds: where do the lanes of k_trace go?  words 32.. of the guard buffer, printed by the host
 #define WF_GUARD_WORDS 64u
 #define WF_PROBE(i, v) probe[i] += (v)
@@ -710,7 +712,12 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);
             }
-            (void)prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v);
+            // (t, u, v) of the hit k_trace found: the same test on the same operands (a leaf record is the first nine floats of P).
+            // Should the repetition ever disagree (other build flags, another code path for the primitive) the call fails with
+            // PBRT_E_DEVICE instead of shading with whatever the registers held: guard word WF_GUARD_REHIT counts the cases.
+            h.t = K_INF;
+            h.u = h.v = 0.0f;
+            if (!prim_hit(P, o, d, K_INF, &h.t, &h.u, &h.v)) atomicAdd(a.guard + WF_GUARD_REHIT, 1u);
             survive = wf_shade_step<ACCEL_K_BVH_GLOBAL>(a, tb, a.depth, ka, kb, h, P, has_vn, vn, o, d, thr, L, eta, prev_pdf, sh);
         }
         n_seg_w += take;

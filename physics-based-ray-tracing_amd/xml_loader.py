@@ -47,11 +47,12 @@ def _vec3(el, env, default=None):
     return [float(_subst(el.attrib.get(a, str(d[i])), env)) for i, a in enumerate("xyz")]
 
 
-def _transform(el, env) -> ScalarTransform4f:
-    # Mitsuba: listed order, every new operation left-multiplies (M = op_n ... op_2 op_1).  transform_order="intent" (a
-    # load_file keyword) composes the other way round, M = op_1 op_2 ... op_n: the reading under which the phantoms of
-    # MitsubaScenes/*.xml, which list translate, rotate, scale, describe what USMain.py:69-71 builds (T @ R @ S).
-    intent = str(env.get("transform_order", "listed")) == "intent"
+def _transform(el, env, order="listed") -> ScalarTransform4f:
+    # Mitsuba: listed order, every new operation left-multiplies (M = op_n ... op_2 op_1).  order="intent" (the
+    # transform_order keyword of load_file: a loader option, NOT one of the $substitutions of `env`) composes the other way
+    # round, M = op_1 op_2 ... op_n: the reading under which the phantoms of MitsubaScenes/*.xml, which list translate,
+    # rotate, scale, describe what USMain.py:69-71 builds (T @ R @ S).
+    intent = order == "intent"
     m = np.eye(4)
     for op in el:
         a = {k: _subst(v, env) for k, v in op.attrib.items()}
@@ -83,7 +84,7 @@ def _snake(name: str) -> str:
     return _CAMEL.sub("_", name).lower() if any(c.isupper() for c in name) else name
 
 
-def _plugin(el, env, base_dir, counters) -> dict:
+def _plugin(el, env, base_dir, counters, order="listed") -> dict:
     d = {"type": _subst(el.attrib["type"], env)} if el.tag != "scene" else {"type": "scene"}
     if "id" in el.attrib:
         d["id"] = el.attrib["id"]
@@ -97,7 +98,7 @@ def _plugin(el, env, base_dir, counters) -> dict:
             if not key or key in d:
                 counters[tag] = counters.get(tag, 0) + 1
                 key = f"{tag}_{counters[tag]}"
-            d[key] = _plugin(ch, env, base_dir, counters)
+            d[key] = _plugin(ch, env, base_dir, counters, order)
         elif tag == "ref":
             counters["ref"] = counters.get("ref", 0) + 1
             d[name or f"ref_{counters['ref']}"] = {"type": "ref", "id": ch.attrib["id"]}
@@ -119,11 +120,11 @@ def _plugin(el, env, base_dir, counters) -> dict:
         elif tag in ("point", "vector"):
             d[name] = _vec3(ch, env)
         elif tag == "transform":
-            d[name] = _transform(ch, env)
+            d[name] = _transform(ch, env, order)
         elif tag == "float_array":
             d[name] = np.asarray(_floats(_subst(ch.attrib["value"], env)), dtype=np.float32)
         elif tag == "include":
-            sub = load_xml_to_dict(os.path.join(base_dir, _subst(ch.attrib["filename"], env)), **env)
+            sub = load_xml_to_dict(os.path.join(base_dir, _subst(ch.attrib["filename"], env)), transform_order=order, **env)
             for k, v in sub.items():
                 if k != "type":
                     d[k] = v
@@ -132,7 +133,12 @@ def _plugin(el, env, base_dir, counters) -> dict:
     return d
 
 
-def load_xml_to_dict(path: str, **overrides) -> dict:
+def load_xml_to_dict(path: str, transform_order: str = "listed", **overrides) -> dict:
+    """overrides: values for the scene's <default name=...> substitutions (mi.load_file(path, res=512, spp=256)).
+    transform_order: "listed" (Mitsuba) or "intent" (DESIGN D14) -- a loader option, kept apart from the substitutions so
+    that neither a <default name="transform_order"> in a scene file nor a caller's substitution of that name can flip it."""
+    if transform_order not in ("listed", "intent"):
+        raise ValueError(f"transform_order must be 'listed' or 'intent', not {transform_order!r}")
     tree = ET.parse(path)
     root = tree.getroot()
     if root.tag != "scene":
@@ -142,4 +148,4 @@ def load_xml_to_dict(path: str, **overrides) -> dict:
         env[el.attrib["name"]] = el.attrib["value"]
     for k, v in overrides.items():
         env[k] = v
-    return _plugin(root, env, os.path.dirname(os.path.abspath(path)), {})
+    return _plugin(root, env, os.path.dirname(os.path.abspath(path)), {}, transform_order)

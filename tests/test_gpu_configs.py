@@ -105,6 +105,7 @@ def test_bench_multi_gpu_rehearsal_launches_itself(tmp_path):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
+    env["PBRT_SCALE_REF_MSAMPLES"] = "1000"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "1",
                         "--warmup", "0", "--spp", "4"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -118,6 +119,9 @@ def test_bench_multi_gpu_rehearsal_launches_itself(tmp_path):
     assert len(out["per_rank_ms"]) == 2 and len(out["collective_ms"]) == 2 and all(t > 0 for t in out["per_rank_ms"])
     assert out["gather_ms"] == out["collective_ms"][0]
     assert out["roofline"]["bound"] == "hbm" and out["roofline"]["frac"] is not None
+    # the scaling record: the one-GPU value of the same workload (handed over in the environment) and the ratio against it
+    assert out["scale_ref"]["config"] == "cbox4k" and out["scale_ref"]["value"] == 1000.0 and out["scale_ref"]["n_gpus"] == 1
+    assert out["speedup_vs_scale_ref"] == pytest.approx(out["value"] / 1000.0, rel=1e-3)
 
 
 def test_bench_rehearsal_of_the_ultrasound_split(tmp_path):

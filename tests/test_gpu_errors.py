@@ -156,3 +156,48 @@ def test_workspace_limit_and_trim(mi):
         assert ctx.trim() < held // 8                                                      # the large pass buffers are not kept for a small call
     finally:
         ctx.set_workspace_limit(0)
+
+
+def test_a_failed_allocation_halves_the_pass_of_an_acquisition(mi, monkeypatch):
+    """ultrasound on a BVH scene sizes its pass from a free-memory snapshot; an allocation that fails afterwards
+    (another allocator got there first -- PBRT_DEBUG_ALLOC_FAIL_BYTES makes every request above its size fail the way hipMalloc
+    would) must halve the pass and go on like render_impl does, and when even the smallest pass does not fit, the call returns
+    PBRT_E_NOMEM and hands back what it had already taken."""
+    ctx = mi.default_context()
+    us = mi.load_file(scene_path("us_testring.xml"))
+    ui = us.integrator()
+    try:
+        ctx.set_workspace_limit(1)
+        assert ctx.trim() == 0
+        ctx.set_workspace_limit(0)
+        one = ui._acquire(us, ui.quirks, paths_per_ray=16384, seed=4)               # 5 x 64 x 16384 = 5 Mi paths: one pass
+        assert ctx.stats()["passes"] == 1
+        ctx.set_workspace_limit(1)
+        assert ctx.trim() == 0
+        ctx.set_workspace_limit(0)
+        monkeypatch.setenv("PBRT_DEBUG_ALLOC_FAIL_BYTES", str(100 << 20))           # a state plane set of 1 Mi paths (64 MB) fits, 2 Mi does not
+        few = ui._acquire(us, ui.quirks, paths_per_ray=16384, seed=4)
+        st = ctx.stats()
+        assert st["passes"] >= 5 and st["workspace_bytes"] < 600 << 20
+        assert np.array_equal(few != 0, one != 0) and np.allclose(few, one, rtol=2e-5, atol=1e-7 * np.abs(one).max())
+        # the brute-force kernels' ping-pong state goes through the same loop
+        sb = mi.load_file(scene_path("us_sphere_box.xml"))
+        ub = sb.integrator()
+        monkeypatch.delenv("PBRT_DEBUG_ALLOC_FAIL_BYTES")
+        ref = ub._acquire(sb, ub.quirks, paths_per_ray=65536, seed=4)               # 20 Mi paths: two passes of 16 Mi
+        monkeypatch.setenv("PBRT_DEBUG_ALLOC_FAIL_BYTES", str(300 << 20))           # 16 Mi x 60 B = 1 GB fails, 4 Mi paths fit
+        ctx.set_workspace_limit(1)
+        ctx.set_workspace_limit(0)
+        got = ub._acquire(sb, ub.quirks, paths_per_ray=65536, seed=4)
+        assert ctx.stats()["passes"] >= 5
+        assert np.array_equal(got != 0, ref != 0) and np.allclose(got, ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())
+        # nothing fits: an error code with a message, and the partial allocations are gone
+        ctx.set_workspace_limit(1)
+        ctx.set_workspace_limit(0)
+        monkeypatch.setenv("PBRT_DEBUG_ALLOC_FAIL_BYTES", str(20 << 20))   # the channel buffer fits, no pass does
+        with pytest.raises(RuntimeError, match="hipMalloc"):
+            ui._acquire(us, ui.quirks, paths_per_ray=16384, seed=4)
+        assert ctx.trim() < 64 << 20
+    finally:
+        monkeypatch.delenv("PBRT_DEBUG_ALLOC_FAIL_BYTES", raising=False)
+        ctx.set_workspace_limit(0)

@@ -361,3 +361,25 @@ def test_testring_asset_carries_its_vertex_normals(mi):
     assert cosang.min() > 0.99 and (cosang > 0.999999).all(axis=1).sum() > 500
     twin = mi.load_file(scene_path("testring.xml"), res=16, spp=1, ring="meshes/ring.obj").flatten()
     assert twin["vertex_normals"] is None                      # the procedural twin has no vn: face normals
+
+
+def test_transform_order_is_a_loader_option_not_a_substitution(mi, tmp_path):
+    """transform_order is an argument of the loader: a <default name="transform_order"> inside a scene file must not flip the
+    composition of its <transform>s, and an unknown value is refused instead of meaning 'listed'."""
+    xml = """<scene version="3.0.0">
+  <default name="transform_order" value="intent"/>
+  <integrator type="path"/>
+  <sensor type="perspective"><film type="hdrfilm"><integer name="width" value="8"/><integer name="height" value="8"/></film></sensor>
+  <shape type="rectangle">
+    <transform name="to_world"><translate x="1" y="0" z="0"/><scale value="2"/></transform>
+    <bsdf type="diffuse"/>
+  </shape>
+</scene>"""
+    p = tmp_path / "order.xml"
+    p.write_text(xml)
+    listed = mi.load_file(str(p)).flatten()["prims"]["g"][0]
+    intent = mi.load_file(str(p), transform_order="intent").flatten()["prims"]["g"][0]
+    # listed (Mitsuba): translate, then scale about the origin -> corner (-2 + 2, -2, 0); intent: T @ S -> corner (-2 + 1, -2, 0)
+    assert np.allclose(listed[:3], [0.0, -2.0, 0.0]) and np.allclose(intent[:3], [-1.0, -2.0, 0.0])
+    with pytest.raises(ValueError):
+        mi.load_file(str(p), transform_order="Listed")

@@ -65,12 +65,19 @@ CONFIGS = {
     "cbox4k": dict(kind="radiance", scene="cbox.xml", res=4096, spp=1024, max_depth=6, band_rows=64, baseline_config=5,
                    metric="Msamples/s on cbox.xml 4096x4096 x 1024 spp (radiance, path max_depth 6), band-sharded",
                    what="tent filter, 6 analytic quads + 2 spheres"),
-    "testring": dict(kind="radiance", scene="testring.xml", res=1024, spp=512, max_depth=6, band_rows=0, baseline_config=4,
+    # pass_paths: the bench process owns its GPU, so the whole 512 Mi-path job is ONE pass (183 GB of workspace); the library's own
+    # default stops at half of the device (two passes of 256 Mi) so that a second tenant finds room
+    "testring": dict(kind="radiance", scene="testring.xml", res=1024, spp=512, max_depth=6, band_rows=0, baseline_config=4, pass_paths=512 << 20,
                      metric="Msamples/s on TestRing/TestRing.obj 1024x1024 x 512 spp (radiance, path max_depth 6, LDS-resident BVH)",
                      what="tent filter, TestRing.obj 1152 triangles + ground + area light"),
     "us_testring": dict(kind="ultrasound", scene="us_testring.xml", ppr=838912, baseline_config=4,
                         metric="Msamples/s on the TestRing.obj phantom (ultrasound twin of config 4), 5 x 64 rays x 838912 paths (UltraBSDF, max_depth 10, LDS-resident BVH)",
                         what="TestRing.obj 1152 triangles + 5 walls, UltraBSDF, 5 angles x 64 elements, channel buffer 5 x 64 x 10000"),
+    # SURVEY 8(f-1 / f-2), the caller of the hot path: one iteration of the reference's finite-difference loop (USMain.py:262-289) =
+    # 2 x (params.update() + us_render: acquisition -> DAS -> envelope -> log compression) on the USMain.py:26-90 scene
+    "usmain_loop": dict(kind="usmain_loop", scene="us_plate.xml", ppr=(1, 64, 4096), baseline_config=None,
+                        metric="ms per finite-difference iteration of USMain.py:262-289 (2 x us_render + 2 x params.update) at paths_per_ray 1",
+                        what="USMain.py:26-90 plate + wall, 5 angles x 64 elements, channel buffer 5 x 64 x 10000, lambda / 4 scan grid"),
     "us_sphere_box": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,
                           metric="Msamples/s on MitsubaScenes/Sphere_Box.xml phantom, 5 x 64 rays x 838912 paths (ultrasound, UltraBSDF, max_depth 10)",
                           what="sphere + 5 walls, UltraBSDF, 5 angles x 64 elements, channel buffer 5 x 64 x 10000"),
@@ -210,6 +217,15 @@ def main():
     mi = importlib.import_module(PKG)
     par = importlib.import_module(PKG + ".parallel")
     env = dict(mi=mi, par=par, np=np, torch=torch, dist=dist, device=device, rank=rank, world=world, args=args, force=force)
+    if cfg["kind"] == "usmain_loop":
+        if world > 1:
+            sys.exit("bench.py --config usmain_loop: the reference's optimisation loop is one serial chain of renders (replicas only)")
+        out = measure_usmain_loop(env, cfg, args.steps or 20, args.warmup if args.warmup >= 0 else 3, with_cpu=not args.no_cpu_baseline)
+        print(json.dumps(out), flush=True)
+        if force:
+            dist.barrier()
+            dist.destroy_process_group()
+        return out
     out = measure(env, name, cfg, steps, warmup, seed=0, overridden=overridden, with_cpu=(world == 1 and not args.no_cpu_baseline))
     if rank == 0 and world == 1 and args.config is None and not overridden and not args.no_also:
         # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line
@@ -225,6 +241,9 @@ def main():
                 # THIS value, not against the headline (config 2, another workload)
                 out["scale_ref"] = {"config": "cbox4k", "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"],
                                     "samples_per_step": o["config"]["samples_per_step"], "n_gpus": 1}
+        # the caller of the hot path: one finite-difference iteration of the reference's loop, device-resident
+        o = measure_usmain_loop(env, dict(CONFIGS["usmain_loop"]), 10, 2, with_cpu=False)
+        out["also"].append({k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "higher_is_better", "roofline", "sizes", "config")})
         out["seeds"] = {"0": {"value": out["value"], "ms_per_step": out["ms_per_step"]}}
         for sd in (1, 2):  # seeds 0, 1, 2
             o = measure(env, name, dict(cfg), 5, 1, seed=sd, overridden=False, with_cpu=False)
@@ -300,7 +319,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         t_a = time.perf_counter()
         if radiance:
             tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
-                                            tile=keep.get("tile"))
+                                            tile=keep.get("tile"), pass_paths=cfg.get("pass_paths", 0) if world == 1 else 0)
             keep["tile"] = tile
             if args.rehearse_on_one_gpu and world > 1:
                 tile = tile.cpu()  # gloo gathers host tensors
@@ -322,6 +341,13 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         mine["coll"] += tm.get("collective_s", 0.0)
         return buf
 
+    if radiance and world == 1 and cfg.get("pass_paths"):
+        try:  # the one-pass size needs 183 GB: on a device that cannot give them, fall back to the library's default (and say so)
+            step()
+        except RuntimeError as e:
+            cfg["pass_paths"] = 0
+            cfg["what"] += f" [pass_paths request refused: {str(e)[:80]}; library default used]"
+            ctx.trim()
     for _ in range(warmup):
         step()
     if warmup == 0 and radiance and (world > 1 or env["force"]):  # no warm-up step to allocate the gather list in
@@ -381,6 +407,8 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
             sharding = ("whole film on one GPU" if world == 1 and band_rows >= RES else
                         f"interleaved {band_rows}-row bands dealt round-robin to {world} rank(s), one gather of the finished bands to rank 0")
             workload = (f"{cfg['scene']} {RES}x{RES}, {SPP} spp, path max_depth {cfg['max_depth']}, {cfg['what']}; {sharding}")
+            if world == 1 and cfg.get("pass_paths"):
+                workload += f"; pass_paths {cfg['pass_paths'] >> 20} Mi asked for by the caller (pbrt_film_desc.pass_paths)"
         else:
             sharding = "all paths on one GPU" if world == 1 else f"contiguous path ranges per rank, one reduce(sum) of the channel buffer to rank 0"
             workload = f"{cfg['scene']} ({cfg['what']}), {PPR} paths per ray; {sharding}"
@@ -444,6 +472,122 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
                                  "what": "gather / reduce issued through torch.distributed at world size 1 (RCCL in this process)"}
         if with_cpu:
             out.update(cpu_baseline(mi, np, scene, cfg, name, seed, args, cpu_seconds))
+    return out
+
+
+def measure_usmain_loop(env, cfg, steps, warmup, with_cpu):
+    """One step = one iteration of the reference's finite-difference loop (USMain.py:279-283): forward(rough) and
+    forward(rough + eps), each params.update() + us_render (acquisition -> DAS -> envelope -> log compression -> the display image
+    on the host).  Timed at paths_per_ray 1 (the reference's own: one ray per (angle, element)), 64 and 4096; the value of the line is
+    the first.  Per size: wall-clock per iteration split into update / acquire / image formation (queueing) / wait + copy, the device
+    time of every image-formation kernel (HIP events on the library's stream, a separate profiled loop), and the same iteration
+    through round 4's host-pointer chain (device_resident=False) as the before / after."""
+    mi, np, torch = env["mi"], env["np"], env["torch"]
+    scene = mi.load_file(os.path.join(SCENES, cfg["scene"]))
+    scene.device()
+    ctx = mi.default_context()
+    integ = scene.integrator()
+    params = mi.traverse(scene)
+    key = [k for k in params.keys() if k.endswith("flat_plate.bsdf.roughness")][0]
+    sizes = []
+
+    def iteration(ppr, rough, acc, **kw):
+        for r in (rough, rough + 1e-3):                                         # USMain.py:280-282
+            t0 = time.perf_counter()
+            params[key] = r
+            params.update()                                                     # :264-265
+            t1 = time.perf_counter()
+            tm = {}
+            img = mi.us_render(scene, seed=0, paths_per_ray=ppr, return_bmode=False, timing=tm, **kw)[0]
+            t2 = time.perf_counter()
+            acc["update"] += t1 - t0
+            acc["render"] += t2 - t1
+            for k, v in tm.items():
+                acc[k] = acc.get(k, 0.0) + v
+            acc["acquire_kernel_ms"] += ctx.stats()["kernel_ms"] if tm else 0.0
+        return img
+
+    for ppr in cfg["ppr"]:
+        acc = dict(update=0.0, render=0.0, acquire_kernel_ms=0.0)
+        for _ in range(warmup):
+            iteration(ppr, 0.1, acc)
+        acc = dict(update=0.0, render=0.0, acquire_kernel_ms=0.0)
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            img = iteration(ppr, 0.1 + 0.01 * i, acc)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        # the same iteration with an event pair around every image-formation kernel (not part of the timed loop above)
+        ctx.set_profiling(True)
+        dev = dict(das_ms=0.0, envelope_ms=0.0, log_ms=0.0)
+        nprof = min(steps, 5)
+        das_bytes = 0
+        for i in range(nprof):
+            iteration(ppr, 0.1 + 0.01 * i, dict(update=0.0, render=0.0, acquire_kernel_ms=0.0))
+            st = ctx.image_stats()
+            for k in dev:
+                dev[k] += st[k]
+            das_bytes = st["das_model_bytes"]
+        ctx.set_profiling(False)
+        # before: round 4's chain through the host-pointer entry points (H2D + kernel + D2H + sync per step)
+        old = dict(update=0.0, render=0.0, acquire_kernel_ms=0.0)
+        nold = max(2, min(steps, 5))
+        iteration(ppr, 0.1, dict(update=0.0, render=0.0, acquire_kernel_ms=0.0), device_resident=False)
+        tb = time.perf_counter()
+        for i in range(nold):
+            iteration(ppr, 0.1 + 0.01 * i, old, device_resident=False)
+        t_old = (time.perf_counter() - tb) / nold
+        n_r = 2 * steps
+        rec = {"paths_per_ray": ppr, "ms_per_iteration": round(dt / steps * 1e3, 4),
+               "per_render_ms": {"params_update": round(acc["update"] / n_r * 1e3, 4), "acquire": round(acc["acquire"] / n_r * 1e3, 4),
+                                 "image_formation_queueing": round(acc["queue"] / n_r * 1e3, 4),
+                                 "wait_and_copy_of_the_image": round(acc["wait_copy"] / n_r * 1e3, 4)},
+               "device_ms_per_render": {"acquisition_kernels": round(acc["acquire_kernel_ms"] / n_r, 4), "das": round(dev["das_ms"] / nprof, 4),
+                                        "envelope": round(dev["envelope_ms"] / nprof, 4), "log_compression": round(dev["log_ms"] / nprof, 4)},
+               "host_pointer_chain_ms_per_iteration": round(t_old * 1e3, 4),
+               "speedup_vs_host_pointer_chain": round(t_old / (dt / steps), 3),
+               "image": list(img.shape), "das_model_bytes": das_bytes,
+               "das_gbs": round(das_bytes / 1e9 / (dev["das_ms"] / nprof / 1e3), 2) if dev["das_ms"] > 0 else None}
+        sizes.append(rec)
+    first = sizes[0]
+    das_ms = first["device_ms_per_render"]["das"]
+    achieved = first["das_gbs"] or 0.0
+    out = {"metric": cfg["metric"], "value": first["ms_per_iteration"], "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": warmup,
+           "ms_per_step": first["ms_per_iteration"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (sample positions f64)",
+           "data": "synthetic",
+           "config": {"workload": f"{cfg['scene']} ({cfg['what']}); one step = forward(rough) + forward(rough + 1e-3), image {first['image'][1]} x {first['image'][0]} pixels; "
+                                  "replicas only (a serial optimisation loop)", "paths_per_ray": list(cfg["ppr"])},
+           "roofline": {"bound": "hbm", "kernel": "k_das_beamform", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "algorithmic_bytes_per_launch": first["das_model_bytes"], "avg_launch_ms": das_ms,
+                        "note": "algorithmic bytes = the channel buffer once + the image once; the kernel gathers 2 x n_angles x |aperture| samples per pixel "
+                                "from L2 at f64 sample positions: it runs against the texture / L2 gather rate and f64 issue, not HBM"},
+           "sizes": sizes}
+    if with_cpu:
+        from oracle import beamform as obf
+        from oracle import binding as ob
+        osc = ob.OracleScene.from_scene(scene)
+        A, E, T = integ.n_angles, integ.n_elements, integ.time_samples
+        lam = integ.sound_speed / integ.frequency
+        xs = np.arange(-0.04, 0.04 + lam / 4, lam / 4)
+        zs = np.arange(0.001, 0.05 + lam / 4, lam / 4)
+        tc = time.perf_counter()
+        ref, tx = osc.us_acquire(integ.us_params(scene), 0, 64)
+        t_acq = time.perf_counter() - tc
+        ex = integ.pitch * (np.arange(E, dtype=np.float32) - (E - 1) / 2)
+        tc = time.perf_counter()
+        rf = obf.das_beamform(ref.reshape(A, E, T), np.asarray(tx).reshape(A, E), ex, xs, zs, integ.fs, integ.sound_speed)
+        envl = obf.envelope(rf)
+        img_ref = obf.log_compress(envl, 60.0).T
+        t_img = time.perf_counter() - tc
+        display = mi.us_render(scene, seed=0, paths_per_ray=64, return_bmode=False)[0]
+        out["cpu_baseline"] = {"value": round(2 * (t_acq + t_img) * 1e3, 1), "unit": "ms", "cores": 1, "kind": "port",
+                               "sample": f"ONE us_render at paths_per_ray 64 (C++ oracle acquisition {t_acq:.2f} s + numpy f64 image formation {t_img:.1f} s "
+                                         f"on the {len(xs)} x {len(zs)} grid), doubled for the two renders of an iteration"}
+        out["l2_vs_cpu_ref"] = {"display_max_abs": float(np.abs(display - img_ref).max()),
+                                "display_rmse": float(np.sqrt(np.mean((display - img_ref) ** 2))), "compared_on": "the display image at paths_per_ray 64, seed 0"}
     return out
 
 

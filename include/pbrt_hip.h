@@ -13,9 +13,13 @@
  *    from pbrt_last_error().  Nothing throws or exits across the ABI.
  *  - batched leaf ops take HOST pointers to C-contiguous SoA arrays ([component][n], f32/u32);
  *    the library stages them through its own device buffers.
- *  - *_dev variants take DEVICE pointers (e.g. torch tensor data_ptr()) and keep data in HBM.
- *  - one pbrt_ctx per device; calls on a ctx are not re-entrant; all calls are synchronous on
- *    return (the ctx stream has been synchronised).
+ *  - *_dev variants take DEVICE pointers (e.g. torch tensor data_ptr(), or pbrt_dev_alloc) and keep data in HBM.
+ *  - one pbrt_ctx per device; calls on a ctx are not re-entrant; calls are synchronous on return (the ctx
+ *    stream has been synchronised) EXCEPT the image-formation *_dev entry points of ABI 5
+ *    (pbrt_das_beamform_dev, pbrt_envelope_dev, pbrt_log_compress_dev, pbrt_us_apply_pulse_dev) and
+ *    pbrt_dev_upload: those queue their work on the ctx stream, in call order behind everything queued before,
+ *    and return; pbrt_ctx_synchronize / pbrt_dev_download wait for it.  A caller that hands in memory of
+ *    another runtime's stream (a torch tensor) orders the two streams itself.
  *  - the caller owns every buffer it passes; the library owns device memory behind the opaque
  *    handles and retains no caller pointer past a call.
  */
@@ -28,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PBRT_ABI_VERSION 4
+#define PBRT_ABI_VERSION 5
 
 /* ---- error classes ------------------------------------------------------------------------ */
 #define PBRT_OK 0
@@ -427,7 +431,8 @@ typedef struct pbrt_das_params {
  * out[ix][iz] = sum_a sum_e data[a][e](t_tx(a; x, z) + |(x, z) - (elem_x[e], 0)| / c), where the transmit time is the
  * first arrival of the emitted wavefront, t_tx = min_e' (tx_delays[a][e'] + |(x, z) - (elem_x[e'], 0)| / c)  (equal to
  * (x sin(theta) + z cos(theta)) / c for the plane-wave delays of pbrt_us_tx_delays inside the aperture's shadow).
- * Sample positions are evaluated in f64, samples interpolated and summed in f32.  Host pointers. */
+ * Sample positions are evaluated in f64, samples interpolated and summed in f32 in the order (groups of 8 transmissions, element,
+ * transmission within the group).  Host pointers. */
 int pbrt_das_beamform(pbrt_ctx *ctx, const pbrt_das_params *p, const float *data, const float *tx_delays,
                       const float *elem_x, const float *x, const float *z, float *out);
 
@@ -448,6 +453,52 @@ int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic
  * (CustomIntegrator.py:20) into the pulse length. */
 int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
                         const float *in, float *out);
+
+/* ---- ABI 5: the reference's us_render loop without leaving HBM -------------------------------------------------------
+ * USMain.py:92-252 runs acquisition -> DAS -> envelope -> log compression 51 times per script (:260, :279-283).  With the
+ * host-pointer forms above every step crosses PCIe twice (the 12.8 MB channel buffer up, an image down).  The *_dev forms take
+ * device pointers, queue their kernels on the context's stream and return without synchronising:
+ *     pbrt_us_acquire_dev(scene, ..., d_channel, tx)            (synchronous, as before)
+ *     [pbrt_us_apply_pulse_dev(ctx, ..., d_channel, d_rf)]       pulse_model = "gaussian" only
+ *     pbrt_das_beamform_dev(ctx, &das, d_rf, d_tx, d_elem_x, d_x, d_z, d_bf)
+ *     pbrt_envelope_dev(ctx, nx, nz, d_bf, d_env)
+ *     pbrt_log_compress_dev(ctx, nx * nz, d_env, 60, d_img)
+ *     pbrt_dev_download(ctx, img, d_img, nx * nz * 4)            the ONE copy to the host; waits for the stream
+ * Same kernels, same results bit for bit as the host-pointer forms (which stage their arguments and call the same code). */
+/* replaces: ultraspy DelayAndSum.beamform(d_data, scan) (USMain.py:204), data and tables in HBM.  All pointers are device
+ * pointers: d_data [n_angles][n_elements][time_samples], d_tx_delays [n_angles][n_elements], d_elem_x [n_elements],
+ * d_x [nx], d_z [nz], d_out [nx][nz]. */
+int pbrt_das_beamform_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_data, const void *d_tx_delays,
+                          const void *d_elem_x, const void *d_x, const void *d_z, void *d_out);
+/* replaces: DelayAndSum.compute_envelope (USMain.py:205); d_rf, d_env [nx][nz], distinct buffers */
+int pbrt_envelope_dev(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const void *d_rf, void *d_env);
+/* replaces: the log compression of USMain.py:210-218; d_env, d_out [n] (may be the same buffer) */
+int pbrt_log_compress_dev(pbrt_ctx *ctx, uint32_t n, const void *d_env, float dynamic_range_db, void *d_out);
+/* the pulse model (RayTracingV0.py:194-204) on a channel buffer in HBM; d_in, d_out [n_traces][time_samples], distinct */
+int pbrt_us_apply_pulse_dev(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
+                            const void *d_in, void *d_out);
+
+/* waits for everything queued on the context's stream */
+int pbrt_ctx_synchronize(pbrt_ctx *ctx);
+/* Device buffers for a caller without a GPU library of its own (the reference's driver is NumPy: USMain.py:103-121).
+ * pbrt_dev_upload copies in stream order (a pageable source is staged before it returns: the caller may reuse it at once);
+ * pbrt_dev_download copies in stream order and waits; pbrt_dev_free waits for the stream first. */
+int pbrt_dev_alloc(pbrt_ctx *ctx, uint64_t bytes, void **out);
+int pbrt_dev_free(pbrt_ctx *ctx, void *p);
+int pbrt_dev_upload(pbrt_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
+int pbrt_dev_download(pbrt_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+
+/* Per-step device times of the image-formation entry points (host and *_dev forms alike), HIP events on the ctx stream.
+ * Off by default (an event pair per step costs a few microseconds of queue time each); pbrt_ctx_set_profiling(ctx, 1) turns
+ * them on, pbrt_get_image_stats waits for the stream and reports the most recent call of each step since then. */
+typedef struct pbrt_image_stats {
+    double pulse_ms, das_ms, envelope_ms, log_ms;
+    uint64_t das_model_bytes; /* algorithmic bytes of the last DAS call: the channel buffer once + the image once */
+    uint32_t measured;        /* bit 0 pulse, 1 das, 2 envelope, 3 log: steps that ran with profiling on */
+    uint32_t pad;
+} pbrt_image_stats;
+int pbrt_ctx_set_profiling(pbrt_ctx *ctx, int on);
+int pbrt_get_image_stats(pbrt_ctx *ctx, pbrt_image_stats *out);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _capi, drjit_compat
 from ._capi import (USQ_CLAMP_TIME, USQ_DIAG_SAMPLE, USQ_DOUBLE_LOCAL, USQ_MIXED_FRAMES, USQ_NEVER_ENTER,
-                    USQ_NO_TOF_ACCUM, USQ_REF_REFLECT, USQ_REFERENCE, USQ_UNIT_GGX_PDF, Context, HipLibraryMissing,
+                    USQ_NO_TOF_ACCUM, USQ_REF_REFLECT, USQ_REFERENCE, USQ_UNIT_GGX_PDF, Context, DeviceBuffer, HipLibraryMissing,
                     default_context, load_library)
 from .plugins import (AreaEmitter, BSDF, BSDFContext, BSDFFlags, BSDFSample3f, ConductorBSDF, CustomEmitter,
                       DielectricBSDF, DiffuseBSDF, DirectIntegrator, DrArray, Emitter, EmitterFlags,

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBRT_HIP_LIB") or os.path.join(_HERE, "csrc", "libpbrt_hip.so")  # override: A/B builds
 
-PBRT_ABI_VERSION = 4
+PBRT_ABI_VERSION = 5
 
 # primitive / material / emitter / filter / accel enums (include/pbrt_hip.h)
 PRIM_TRIANGLE, PRIM_SPHERE, PRIM_PARALLELOGRAM, PRIM_CONE = 0, 1, 2, 3
@@ -145,6 +145,11 @@ class Stats(C.Structure):
         return d
 
 
+class ImageStats(C.Structure):
+    _fields_ = [("pulse_ms", C.c_double), ("das_ms", C.c_double), ("envelope_ms", C.c_double), ("log_ms", C.c_double),
+                ("das_model_bytes", C.c_uint64), ("measured", C.c_uint32), ("pad", C.c_uint32)]
+
+
 _P = C.c_void_p
 _F = C.c_void_p  # float* passed as raw address of a numpy buffer
 
@@ -180,6 +185,18 @@ SIGNATURES = {
     "pbrt_envelope": (C.c_int, [_P, C.c_uint32, C.c_uint32, _F, _F]),
     "pbrt_log_compress": (C.c_int, [_P, C.c_uint32, _F, C.c_float, _F]),
     "pbrt_us_apply_pulse": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _F, _F]),
+    # ABI 5: image formation on device pointers (queued on the ctx stream, no synchronisation), device buffers, the stream
+    "pbrt_das_beamform_dev": (C.c_int, [_P, C.POINTER(DasParams), _P, _P, _P, _P, _P, _P]),
+    "pbrt_envelope_dev": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "pbrt_log_compress_dev": (C.c_int, [_P, C.c_uint32, _P, C.c_float, _P]),
+    "pbrt_us_apply_pulse_dev": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "pbrt_ctx_synchronize": (C.c_int, [_P]),
+    "pbrt_dev_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "pbrt_dev_free": (C.c_int, [_P, _P]),
+    "pbrt_dev_upload": (C.c_int, [_P, _P, _F, C.c_uint64]),
+    "pbrt_dev_download": (C.c_int, [_P, _F, _P, C.c_uint64]),
+    "pbrt_ctx_set_profiling": (C.c_int, [_P, C.c_int]),
+    "pbrt_get_image_stats": (C.c_int, [_P, C.POINTER(ImageStats)]),
 }
 
 _lib = None
@@ -313,10 +330,68 @@ class Context:
         self.check(self.lib.pbrt_ctx_trim(self.handle, C.byref(held)), "pbrt_ctx_trim")
         return int(held.value)
 
+    def synchronize(self) -> None:
+        """wait for everything queued on the context's stream (the image-formation *_dev calls do not)"""
+        self.check(self.lib.pbrt_ctx_synchronize(self.handle), "pbrt_ctx_synchronize")
+
+    def set_profiling(self, on: bool) -> None:
+        """HIP-event pairs around the image-formation steps (pbrt_get_image_stats); off by default"""
+        self.check(self.lib.pbrt_ctx_set_profiling(self.handle, int(bool(on))), "pbrt_ctx_set_profiling")
+
+    def image_stats(self) -> dict:
+        st = ImageStats()
+        self.check(self.lib.pbrt_get_image_stats(self.handle, C.byref(st)), "pbrt_get_image_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_ if k != "pad"}
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.pbrt_ctx_destroy(self.handle)
             self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """A float32 / uint32 array in HBM owned by the library (pbrt_dev_alloc): what keeps the us_render loop on the device for a
+    NumPy caller.  `ptr` is the device address the *_dev entry points take."""
+
+    def __init__(self, ctx: Context, shape, dtype=np.float32):
+        self.ctx = ctx
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        h = _P()
+        ctx.check(ctx.lib.pbrt_dev_alloc(ctx.handle, C.c_uint64(self.nbytes), C.byref(h)), "pbrt_dev_alloc")
+        self.ptr = h.value
+
+    @classmethod
+    def from_host(cls, ctx: Context, a) -> "DeviceBuffer":
+        a = np.ascontiguousarray(a)
+        b = cls(ctx, a.shape, a.dtype)
+        b.upload(a)
+        return b
+
+    def upload(self, a) -> None:
+        """in stream order; the source may be reused as soon as this returns"""
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError(f"upload of {a.nbytes} bytes into a buffer of {self.nbytes}")
+        self.ctx.check(self.ctx.lib.pbrt_dev_upload(self.ctx.handle, _P(self.ptr), addr(a), C.c_uint64(self.nbytes)), "pbrt_dev_upload")
+
+    def numpy(self) -> np.ndarray:
+        """copy to the host (waits for the queued work)"""
+        out = np.empty(self.shape, self.dtype)
+        self.ctx.check(self.ctx.lib.pbrt_dev_download(self.ctx.handle, addr(out), _P(self.ptr), C.c_uint64(self.nbytes)), "pbrt_dev_download")
+        return out
+
+    def close(self):
+        if getattr(self, "ptr", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.pbrt_dev_free(self.ctx.handle, _P(self.ptr))
+        self.ptr = None
 
     def __del__(self):
         try:

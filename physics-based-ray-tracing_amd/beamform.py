@@ -19,10 +19,51 @@ import numpy as np
 from . import _capi
 
 
+def _das_params(A, E, T, nx, nz, fs, sound_speed, t0, f_number, interpolation, compound) -> "_capi.DasParams":
+    p = _capi.DasParams()
+    p.n_angles, p.n_elements, p.time_samples = int(A), int(E), int(T)
+    p.fs, p.sound_speed, p.t0, p.f_number = float(fs), float(sound_speed), float(t0), float(f_number or 0.0)
+    p.interpolation = {"nearest": _capi.DAS_NEAREST, "linear": _capi.DAS_LINEAR}[interpolation]
+    p.compound_mean = {"sum": 0, "mean": 1}[compound]
+    p.nx, p.nz = int(nx), int(nz)
+    return p
+
+
+def _is_dev(a) -> bool:
+    return isinstance(a, _capi.DeviceBuffer)
+
+
+def _to_dev(cx, a, shape=None) -> "_capi.DeviceBuffer":
+    if _is_dev(a):
+        return a
+    a = _capi.f32(np.asarray(a))
+    return _capi.DeviceBuffer.from_host(cx, a if shape is None else a.reshape(shape))
+
+
 def das_beamform(data, tx_delays, elem_x, x, z, fs, sound_speed, t0=0.0, f_number=1.0, interpolation="linear",
-                 compound="sum") -> np.ndarray:
+                 compound="sum", out=None):
     """data [n_angles, n_elements, T] f32, tx_delays [n_angles, n_elements] (s), elem_x [n_elements] (m),
-    grid x [nx], z [nz] (m)  ->  beamformed RF image [nx, nz] (pbrt_das_beamform)."""
+    grid x [nx], z [nz] (m)  ->  beamformed RF image [nx, nz].
+    Host arrays in: pbrt_das_beamform, a host array out.  `data` a DeviceBuffer (the channel buffer of an acquisition that
+    stayed in HBM): pbrt_das_beamform_dev -- the small tables are uploaded if they are host arrays, the kernel is queued on
+    the context's stream and the result is a DeviceBuffer (`out`, or a new one); nothing waits."""
+    cx = data.ctx if _is_dev(data) else _capi.default_context()
+    if _is_dev(data):
+        if len(data.shape) != 3:
+            raise ValueError("data must be [n_angles, n_elements, time_samples]")
+        A, E, T = data.shape
+        d_tx, d_ex = _to_dev(cx, tx_delays, (A, E)), _to_dev(cx, elem_x, (E,))
+        d_x = x if _is_dev(x) else _to_dev(cx, np.asarray(x).ravel())
+        d_z = z if _is_dev(z) else _to_dev(cx, np.asarray(z).ravel())
+        nx, nz = d_x.shape[0], d_z.shape[0]
+        p = _das_params(A, E, T, nx, nz, fs, sound_speed, t0, f_number, interpolation, compound)
+        d_out = out if out is not None else _capi.DeviceBuffer(cx, (nx, nz))
+        if d_out.nbytes != nx * nz * 4:
+            raise ValueError("out must hold nx * nz float32")
+        cx.check(cx.lib.pbrt_das_beamform_dev(cx.handle, C.byref(p), data.ptr, d_tx.ptr, d_ex.ptr, d_x.ptr, d_z.ptr, d_out.ptr),
+                 "pbrt_das_beamform_dev")
+        d_out._keep = (d_tx, d_ex, d_x, d_z)  # the queued kernel reads them: they live as long as its result
+        return d_out
     data = _capi.f32(np.asarray(data))
     if data.ndim != 3:
         raise ValueError("data must be [n_angles, n_elements, time_samples]")
@@ -30,49 +71,63 @@ def das_beamform(data, tx_delays, elem_x, x, z, fs, sound_speed, t0=0.0, f_numbe
     tx = _capi.f32(np.asarray(tx_delays).reshape(A, E))
     ex = _capi.f32(np.asarray(elem_x).reshape(E))
     gx, gz = _capi.f32(np.asarray(x).ravel()), _capi.f32(np.asarray(z).ravel())
-    p = _capi.DasParams()
-    p.n_angles, p.n_elements, p.time_samples = A, E, T
-    p.fs, p.sound_speed, p.t0, p.f_number = float(fs), float(sound_speed), float(t0), float(f_number or 0.0)
-    p.interpolation = {"nearest": _capi.DAS_NEAREST, "linear": _capi.DAS_LINEAR}[interpolation]
-    p.compound_mean = {"sum": 0, "mean": 1}[compound]
-    p.nx, p.nz = len(gx), len(gz)
-    out = np.empty((p.nx, p.nz), dtype=np.float32)
-    cx = _capi.default_context()
+    p = _das_params(A, E, T, len(gx), len(gz), fs, sound_speed, t0, f_number, interpolation, compound)
+    res = np.empty((p.nx, p.nz), dtype=np.float32)
     cx.check(cx.lib.pbrt_das_beamform(cx.handle, C.byref(p), _capi.addr(data), _capi.addr(tx), _capi.addr(ex), _capi.addr(gx),
-                                      _capi.addr(gz), _capi.addr(out)), "pbrt_das_beamform")
-    return out
+                                      _capi.addr(gz), _capi.addr(res)), "pbrt_das_beamform")
+    return res
 
 
-def envelope(rf) -> np.ndarray:
-    """|analytic signal| along the last (axial) axis of a [nx, nz] RF image (pbrt_envelope)."""
+def envelope(rf, out=None):
+    """|analytic signal| along the last (axial) axis of a [nx, nz] RF image (pbrt_envelope; a DeviceBuffer in gives a
+    DeviceBuffer out, queued on the context's stream)."""
+    cx = rf.ctx if _is_dev(rf) else _capi.default_context()
+    if _is_dev(rf):
+        nx, nz = (rf.shape if len(rf.shape) == 2 else (1, rf.shape[0]))
+        d_out = out if out is not None else _capi.DeviceBuffer(cx, rf.shape)
+        cx.check(cx.lib.pbrt_envelope_dev(cx.handle, nx, nz, rf.ptr, d_out.ptr), "pbrt_envelope_dev")
+        d_out._keep = (rf,)
+        return d_out
     rf = _capi.f32(np.atleast_2d(np.asarray(rf)))
     nx, nz = rf.shape
-    out = np.empty_like(rf)
-    cx = _capi.default_context()
-    cx.check(cx.lib.pbrt_envelope(cx.handle, nx, nz, _capi.addr(rf), _capi.addr(out)), "pbrt_envelope")
-    return out
+    res = np.empty_like(rf)
+    cx.check(cx.lib.pbrt_envelope(cx.handle, nx, nz, _capi.addr(rf), _capi.addr(res)), "pbrt_envelope")
+    return res
 
 
-def log_compress(env, dynamic_range=60.0) -> np.ndarray:
+def log_compress(env, dynamic_range=60.0, out=None):
     """USMain.py:210-218: 20 log10(env + 1e-12) clipped to the top `dynamic_range` dB, mapped to [0, 1]."""
+    cx = env.ctx if _is_dev(env) else _capi.default_context()
+    if _is_dev(env):
+        d_out = out if out is not None else _capi.DeviceBuffer(cx, env.shape)
+        n = env.nbytes // 4
+        cx.check(cx.lib.pbrt_log_compress_dev(cx.handle, n, env.ptr, float(dynamic_range), d_out.ptr), "pbrt_log_compress_dev")
+        d_out._keep = (env,)
+        return d_out
     env = _capi.f32(np.asarray(env))
-    out = np.empty_like(env)
-    cx = _capi.default_context()
-    cx.check(cx.lib.pbrt_log_compress(cx.handle, env.size, _capi.addr(env), float(dynamic_range), _capi.addr(out)),
+    res = np.empty_like(env)
+    cx.check(cx.lib.pbrt_log_compress(cx.handle, env.size, _capi.addr(env), float(dynamic_range), _capi.addr(res)),
              "pbrt_log_compress")
-    return out
+    return res
 
 
-def apply_pulse(traces, fs, frequency, sigma) -> np.ndarray:
+def apply_pulse(traces, fs, frequency, sigma, out=None):
     """SURVEY f-3 pulse model (RayTracingV0.py:194-204): every trace (last axis) convolved with
-    h[k] = sin(2 pi f k / fs) exp(-(k / fs)^2 / sigma^2)  (pbrt_us_apply_pulse)."""
+    h[k] = sin(2 pi f k / fs) exp(-(k / fs)^2 / sigma^2)  (pbrt_us_apply_pulse; DeviceBuffer in -> DeviceBuffer out)."""
+    cx = traces.ctx if _is_dev(traces) else _capi.default_context()
+    if _is_dev(traces):
+        T = traces.shape[-1]
+        d_out = out if out is not None else _capi.DeviceBuffer(cx, traces.shape)
+        cx.check(cx.lib.pbrt_us_apply_pulse_dev(cx.handle, (traces.nbytes // 4) // T, T, float(fs), float(frequency), float(sigma),
+                                                traces.ptr, d_out.ptr), "pbrt_us_apply_pulse_dev")
+        d_out._keep = (traces,)
+        return d_out
     x = _capi.f32(np.asarray(traces))
     T = x.shape[-1]
-    out = np.empty_like(x)
-    cx = _capi.default_context()
+    res = np.empty_like(x)
     cx.check(cx.lib.pbrt_us_apply_pulse(cx.handle, x.size // T, T, float(fs), float(frequency), float(sigma), _capi.addr(x),
-                                        _capi.addr(out)), "pbrt_us_apply_pulse")
-    return out
+                                        _capi.addr(res)), "pbrt_us_apply_pulse")
+    return res
 
 
 # ---- ultraspy-shaped front end (USMain.py:126-205) ---------------------------------------------------------------
@@ -98,6 +153,7 @@ class GridScan:
     def __init__(self, x_axis, z_axis):
         self.x_axis = np.asarray(x_axis, dtype=np.float64).ravel()
         self.z_axis = np.asarray(z_axis, dtype=np.float64).ravel()
+        self.d_x = self.d_z = None  # the axes as DeviceBuffers (set by us_render)
 
     @property
     def shape(self):
@@ -110,6 +166,7 @@ class DelayAndSum:
         self.setups = {"f_number": f_number, "interpolation": interpolation, "compound": compound}
         self.acquisition_info = None
         self.probe = None
+        self.probe_dev = None  # element positions as a DeviceBuffer (set by us_render)
 
     def automatic_setup(self, acquisition_info, probe):
         self.acquisition_info = dict(acquisition_info)
@@ -121,47 +178,120 @@ class DelayAndSum:
             raise KeyError(name)
         self.setups[name] = value
 
-    def beamform(self, d_data, scan):
+    def beamform(self, d_data, scan, out=None):
+        """host array in -> host array out; a DeviceBuffer in (the channel buffer left in HBM) -> a DeviceBuffer out, queued"""
         ai = self.acquisition_info
         if ai is None or self.probe is None:
             raise RuntimeError("DelayAndSum.automatic_setup(acquisition_info, probe) has not been called")
-        data = np.asarray(d_data)
-        if data.ndim == 4:      # (frames, n_angles, n_elements, T): USMain passes reader.data[0]
-            data = data[0]
-        return das_beamform(data, ai["delays"], self.probe.geometry[0], scan.x_axis, scan.z_axis, ai["sampling_freq"],
-                            ai["sound_speed"], t0=ai.get("t0", 0.0) or 0.0, f_number=self.setups["f_number"],
-                            interpolation=self.setups["interpolation"], compound=self.setups["compound"])
+        data = d_data
+        if not _is_dev(data):
+            data = np.asarray(d_data)
+            if data.ndim == 4:      # (frames, n_angles, n_elements, T): USMain passes reader.data[0]
+                data = data[0]
+        # tables that already sit in HBM (us_render keeps them there between calls) are used where the data is a DeviceBuffer
+        dev = _is_dev(data)
+        ex = self.probe_dev if dev and self.probe_dev is not None else self.probe.geometry[0]
+        gx = scan.d_x if dev and getattr(scan, "d_x", None) is not None else scan.x_axis
+        gz = scan.d_z if dev and getattr(scan, "d_z", None) is not None else scan.z_axis
+        return das_beamform(data, ai["delays"], ex, gx, gz, ai["sampling_freq"], ai["sound_speed"], t0=ai.get("t0", 0.0) or 0.0,
+                            f_number=self.setups["f_number"], interpolation=self.setups["interpolation"],
+                            compound=self.setups["compound"], out=out)
 
-    def compute_envelope(self, d_output, scan=None):
-        return envelope(d_output)
+    def compute_envelope(self, d_output, scan=None, out=None):
+        return envelope(d_output, out=out)
 
     def __str__(self):
         return f"DelayAndSum(MI355X, {self.setups})"
 
 
+class _RenderPlan:
+    """Device buffers of one us_render configuration (acquisition shape, scan grid): allocated once, reused by every call of the
+    reference's loop (USMain.py:262-289 calls us_render 50 times on one scene)."""
+
+    def __init__(self, cx, A, E, T, elem_x, x_scan, z_scan, gaussian):
+        self.key = None
+        self.cx = cx
+        self.d_channel = _capi.DeviceBuffer(cx, (A, E, T))
+        self.d_rf = _capi.DeviceBuffer(cx, (A, E, T)) if gaussian else None
+        self.d_tx = _capi.DeviceBuffer(cx, (A, E))
+        self.tx_host = None
+        self.d_ex = _capi.DeviceBuffer.from_host(cx, _capi.f32(elem_x))
+        self.d_x = _capi.DeviceBuffer.from_host(cx, _capi.f32(x_scan))
+        self.d_z = _capi.DeviceBuffer.from_host(cx, _capi.f32(z_scan))
+        nx, nz = len(x_scan), len(z_scan)
+        self.d_bf = _capi.DeviceBuffer(cx, (nx, nz))
+        self.d_env = _capi.DeviceBuffer(cx, (nx, nz))
+        self.d_img = _capi.DeviceBuffer(cx, (nx, nz))
+
+
 def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range=60.0, step=None, seed=None,
-              paths_per_ray=None, beamformer=None):
+              paths_per_ray=None, beamformer=None, device_resident=True, return_bmode=True, timing=None):
     """The reference's us_render (USMain.py:93-224) without the plotting: acquisition -> DAS -> envelope -> log
-    compression.  Returns (display_image [nz, nx] in [0, 1], bmode envelope [nx, nz], (x_scan, z_scan))."""
+    compression.  Returns (display_image [nz, nx] in [0, 1], bmode envelope [nx, nz] (None with return_bmode=False),
+    (x_scan, z_scan)).
+
+    device_resident (default): the channel buffer never leaves HBM -- pbrt_us_acquire_dev writes it, the image-formation
+    kernels are queued behind it on the context's stream (*_dev entry points, ABI 5), and ONE copy brings the display image to
+    the host (a second one the envelope, if asked for).  `integrator.channel_buf` is fetched only if somebody reads it.
+    device_resident=False is round 4's path through the host-pointer entry points (every step up and down PCIe), kept for the
+    A/B and the bit-for-bit test.  timing: a dict that receives host wall-clock seconds (acquire, queue, wait_copy)."""
+    import time as _time
     integ = scene.integrator()
-    if seed is not None or paths_per_ray is not None:
-        integ.channel_buf = integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed)
-    else:
-        integ.simulate_acquisition_parallel(scene)                                                     # :99
     A, E, T = integ.n_angles, integ.n_elements, integ.time_samples
-    data = np.asarray(integ.channel_buf, dtype=np.float32).reshape(A, E, T)                            # :118
-    delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)                 # :121
-    probe = build_probe("linear", E, integ.pitch, integ.frequency, 70)                                 # :130-136
-    info = {"sampling_freq": integ.fs, "t0": 0, "prf": None, "signal_duration": None, "delays": delays,
-            "sound_speed": integ.sound_speed,
-            "sequence_elements": {"emitted": np.tile(np.arange(E), (A, 1)), "received": np.tile(np.arange(E), (A, 1))}}
-    bf = beamformer or DelayAndSum(on_gpu=True)
-    bf.automatic_setup(info, probe)                                                                    # :175
     lam = integ.sound_speed / integ.frequency
     step = step or lam / 4                                                                             # :189-191
     x_scan = np.arange(x_range[0], x_range[1] + step, step)                                            # :193
     z_scan = np.arange(z_range[0], z_range[1] + step, step)                                            # :194
     scan = GridScan(x_scan, z_scan)
-    bmode = bf.compute_envelope(bf.beamform(data[np.newaxis], scan), scan).astype(np.float32)          # :204-207
-    display = log_compress(bmode, dynamic_range).T                                                     # :210-221
+    probe = build_probe("linear", E, integ.pitch, integ.frequency, 70)                                 # :130-136
+    bf = beamformer or DelayAndSum(on_gpu=True)
+    seq = {"emitted": np.tile(np.arange(E), (A, 1)), "received": np.tile(np.arange(E), (A, 1))}
+
+    def info(delays):
+        return {"sampling_freq": integ.fs, "t0": 0, "prf": None, "signal_duration": None, "delays": delays,
+                "sound_speed": integ.sound_speed, "sequence_elements": seq}
+
+    if not device_resident:
+        if seed is not None or paths_per_ray is not None:
+            integ.channel_buf = integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed)
+        else:
+            integ.simulate_acquisition_parallel(scene)                                                 # :99
+        data = np.asarray(integ.channel_buf, dtype=np.float32).reshape(A, E, T)                        # :118
+        delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)             # :121
+        bf.automatic_setup(info(delays), probe)                                                        # :175
+        bmode = bf.compute_envelope(bf.beamform(data[np.newaxis], scan), scan).astype(np.float32)      # :204-207
+        display = log_compress(bmode, dynamic_range).T                                                 # :210-221
+        return display, bmode, (x_scan, z_scan)
+
+    cx = scene.device().ctx
+    gaussian = integ.pulse_model == "gaussian"
+    key = (A, E, T, float(integ.pitch), x_scan.tobytes(), z_scan.tobytes(), gaussian, id(cx))
+    plan = getattr(integ, "_render_plan", None)
+    if plan is None or plan.key != key:
+        plan = _RenderPlan(cx, A, E, T, probe.geometry[0], x_scan, z_scan, gaussian)
+        plan.key = key
+        integ._render_plan = plan
+    t0 = _time.perf_counter()
+    integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed, out_dev=plan.d_channel.ptr, pulse=False)  # :99
+    t1 = _time.perf_counter()
+    delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)                 # :121
+    if plan.tx_host is None or not np.array_equal(plan.tx_host, delays):
+        plan.d_tx.upload(delays)
+        plan.tx_host = delays.copy()
+    rf = plan.d_channel
+    if gaussian:                                                                                       # f-3: carrier on the device
+        rf = apply_pulse(plan.d_channel, integ.fs, integ.frequency, integ.pulse_sigma, out=plan.d_rf)
+    integ._set_device_channel(rf)
+    bf.automatic_setup(info(plan.d_tx), probe)                                                         # :175
+    scan.d_x, scan.d_z = plan.d_x, plan.d_z
+    bf.probe_dev = plan.d_ex
+    d_bf = bf.beamform(rf, scan, out=plan.d_bf)                                                        # :204
+    d_env = bf.compute_envelope(d_bf, scan, out=plan.d_env)                                            # :205
+    d_img = log_compress(d_env, dynamic_range, out=plan.d_img)                                         # :210-218
+    t2 = _time.perf_counter()
+    display = d_img.numpy().T                                                                          # :221  (the one copy)
+    bmode = d_env.numpy() if return_bmode else None
+    t3 = _time.perf_counter()
+    if timing is not None:
+        timing.update(acquire=t1 - t0, queue=t2 - t1, wait_copy=t3 - t2)
     return display, bmode, (x_scan, z_scan)

@@ -54,6 +54,13 @@ struct pbrt_ctx {
         ws.erase(it);
     }
     std::vector<hipEvent_t> ev_pool;
+    // image formation (f-1): event pairs per step when profiling is on (pbrt_ctx_set_profiling), read by pbrt_get_image_stats
+    bool profiling = false;
+    hipEvent_t img_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t img_mask = 0;
+    uint64_t img_das_bytes = 0;
+    size_t env_lds_attr = 0;
+    bool img_event(int i) { return img_ev[i] || hipEventCreate(&img_ev[i]) == hipSuccess; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t lds_limit = 0;
 
@@ -312,6 +319,8 @@ int pbrt_ctx_destroy(pbrt_ctx *c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto e : c->sync_ev) (void)hipEventDestroy(e);
+    for (auto e : c->img_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->st_trace) (void)hipStreamDestroy(c->st_trace);
     if (c->st_shade) (void)hipStreamDestroy(c->st_shade);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -2227,24 +2236,125 @@ int pbrt_us_put_data(pbrt_ctx *ctx, const pbrt_us_receiver *r, uint32_t n, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// image formation behind the hot path: beamform -> envelope -> log compression
+// image formation behind the hot path: (pulse ->) beamform -> envelope -> log compression.
+// The *_dev entry points queue their kernels on the context's stream and return (ABI 5): the reference's us_render loop
+// (USMain.py:92-252, 51 x per run) stays in HBM from the acquisition to the display image.  The host-pointer forms stage
+// their arguments and call the same queueing functions.
 // ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+// an event pair around one image-formation step when the context profiles (pbrt_ctx_set_profiling); slot = IMG_*
+enum { IMG_PULSE = 0, IMG_DAS = 1, IMG_ENV = 2, IMG_LOG = 3, IMG_STEPS = 4 };
+struct ImgTimer {
+    pbrt_ctx *c;
+    int slot;
+    ImgTimer(pbrt_ctx *ctx, int s) : c(ctx), slot(s) {
+        if (c->profiling && c->img_event(2 * slot)) (void)hipEventRecord(c->img_ev[2 * slot], c->stream);
+    }
+    ~ImgTimer() {
+        if (c->profiling && c->img_event(2 * slot + 1)) {
+            (void)hipEventRecord(c->img_ev[2 * slot + 1], c->stream);
+            c->img_mask |= 1u << slot;
+        }
+    }
+};
+
+static int das_check(pbrt_ctx *ctx, const pbrt_das_params *p) {
+    NEED(ctx, p->n_angles > 0 && p->n_elements > 0 && p->time_samples > 1 && p->fs > 0.0f && p->sound_speed > 0.0f);
+    NEED(ctx, p->interpolation <= PBRT_DAS_LINEAR && p->f_number >= 0.0f);
+    NEED(ctx, p->nx > 0 && p->nz > 0 && (uint64_t)p->nx * p->nz < 0xffffffffull);
+    NEED(ctx, div_up(p->nx, DAS_TILE) <= 65535u);
+    return PBRT_OK;
+}
+static int das_enqueue(pbrt_ctx *c, const pbrt_das_params *p, const float *dd, const float *dt, const float *de, const float *dx,
+                       const float *dz, float *dout) {
+    ImgTimer tm(c, IMG_DAS);
+    const dim3 grid(div_up(p->nz, DAS_TILE), div_up(p->nx, DAS_TILE)), block(256);
+    if (p->interpolation == PBRT_DAS_NEAREST)
+        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_NEAREST>, grid, block, 0, c->stream, *p, dd, dt, de, dx, dz, dout);
+    else
+        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_LINEAR>, grid, block, 0, c->stream, *p, dd, dt, de, dx, dz, dout);
+    c->img_das_bytes = ((uint64_t)p->n_angles * p->n_elements * p->time_samples + (uint64_t)p->nx * p->nz) * 4;
+    HIPCHK(c, hipGetLastError());
+    return PBRT_OK;
+}
+static int env_enqueue(pbrt_ctx *c, uint32_t nx, uint32_t nz, const float *din, float *dout) {
+    ImgTimer tm(c, IMG_ENV);
+    const uint32_t np = (nz + 3u) & ~3u;
+    const size_t lds = (size_t)(3u * np + 8u) * 4;
+    if (lds > c->env_lds_attr) {
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        c->env_lds_attr = lds;
+    }
+    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), dim3(256), lds, c->stream, nz, din, dout);
+    HIPCHK(c, hipGetLastError());
+    return PBRT_OK;
+}
+static int log_enqueue(pbrt_ctx *c, uint32_t n, const float *din, float dr, float *dout) {
+    uint32_t *mx = (uint32_t *)c->buf("img_max", 256);
+    if (!mx) return PBRT_E_NOMEM;
+    ImgTimer tm(c, IMG_LOG);
+    HIPCHK(c, hipMemsetAsync(mx, 0, 4, c->stream));
+    hipLaunchKernelGGL(k_env_max, dim3(std::min<uint32_t>(div_up(n, 256), 1024)), dim3(256), 0, c->stream, n, din, mx);
+    hipLaunchKernelGGL(k_log_compress, dim3(div_up(n, 256)), dim3(256), 0, c->stream, n, din, mx, dr, dout);
+    HIPCHK(c, hipGetLastError());
+    return PBRT_OK;
+}
+static int pulse_check(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma, uint32_t *K) {
+    NEED(ctx, fs > 0.0f && frequency > 0.0f && sigma > 0.0f);
+    NEED(ctx, (uint64_t)n_traces * time_samples < 0xffffffffull && n_traces <= 65535u);
+    *K = (uint32_t)std::ceil(2.5 * (double)sigma * (double)fs);
+    NEED(ctx, *K <= PULSE_MAX_K);
+    return PBRT_OK;
+}
+static int pulse_enqueue(pbrt_ctx *c, uint32_t n_traces, uint32_t T, uint32_t K, float fs, float fc, float sigma, const float *din,
+                         float *dout) {
+    ImgTimer tm(c, IMG_PULSE);
+    const size_t lds = (size_t)(2 * K + 1 + 256 + 2 * K) * 4;
+    hipLaunchKernelGGL(k_apply_pulse, dim3(div_up(T, 256), n_traces), dim3(256), lds, c->stream, T, K, fs, fc, sigma, din, dout);
+    HIPCHK(c, hipGetLastError());
+    return PBRT_OK;
+}
+
+extern "C" {
+
+int pbrt_das_beamform_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_data, const void *d_tx_delays, const void *d_elem_x,
+                          const void *d_x, const void *d_z, void *d_out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, p && d_data && d_tx_delays && d_elem_x && d_x && d_z && d_out);
+    int rc = das_check(ctx, p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return das_enqueue(ctx, p, (const float *)d_data, (const float *)d_tx_delays, (const float *)d_elem_x, (const float *)d_x,
+                       (const float *)d_z, (float *)d_out);
+}
+
 int pbrt_das_beamform(pbrt_ctx *ctx, const pbrt_das_params *p, const float *data, const float *tx_delays,
                       const float *elem_x, const float *x, const float *z, float *out) {
     if (!ctx) return PBRT_E_INVALID;
     NEED(ctx, p && data && tx_delays && elem_x && x && z && out);
-    NEED(ctx, p->n_angles > 0 && p->n_elements > 0 && p->time_samples > 1 && p->fs > 0.0f && p->sound_speed > 0.0f);
-    NEED(ctx, p->interpolation <= PBRT_DAS_LINEAR && p->f_number >= 0.0f);
-    NEED(ctx, (uint64_t)p->nx * p->nz < 0xffffffffull);
+    int rc = das_check(ctx, p);
+    if (rc) return rc;
     const size_t nd = (size_t)p->n_angles * p->n_elements * p->time_samples, ne = (size_t)p->n_angles * p->n_elements;
     const uint32_t n = p->nx * p->nz;
     LEAF_BEGIN(ctx, (nd + ne + p->n_elements + p->nx + p->nz + (size_t)n) * 4 + 256);
+    (void)grid;
+    (void)block;
+    (void)st;
     float *dd = S.in(data, nd), *dt = S.in(tx_delays, ne), *de = S.in(elem_x, p->n_elements);
     float *dx = S.in(x, p->nx), *dz = S.in(z, p->nz);
     float *dout = S.out<float>(n);
-    hipLaunchKernelGGL(k_das_beamform, grid, block, 0, st, *p, dd, dt, de, dx, dz, dout);
+    if ((rc = das_enqueue(c, p, dd, dt, de, dx, dz, dout)) != 0) return rc;
     S.back(out, dout, n);
     return S.finish();
+}
+
+int pbrt_envelope_dev(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const void *d_rf, void *d_env) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, d_rf && d_env && d_rf != d_env && nz <= ENV_MAX_N && (uint64_t)nx * nz < 0xffffffffull);
+    if (nx == 0 || nz == 0) return PBRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return env_enqueue(ctx, nx, nz, (const float *)d_rf, (float *)d_env);
 }
 
 int pbrt_envelope(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const float *rf, float *env) {
@@ -2253,45 +2363,140 @@ int pbrt_envelope(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const float *rf, floa
     const uint32_t n = nx * nz;
     NEED(ctx, (uint64_t)nx * nz < 0xffffffffull);
     LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
-    float *din = S.in(rf, n), *dout = S.out<float>(n);
-    const size_t lds = (size_t)nz * 5 * 4;
-    HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), block, lds, st, nz, din, dout);
     (void)grid;
+    (void)block;
+    (void)st;
+    float *din = S.in(rf, n), *dout = S.out<float>(n);
+    int rc = env_enqueue(c, nx, nz, din, dout);
+    if (rc) return rc;
     S.back(env, dout, n);
     return S.finish();
+}
+
+int pbrt_log_compress_dev(pbrt_ctx *ctx, uint32_t n, const void *d_env, float dynamic_range_db, void *d_out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, d_env && d_out && dynamic_range_db > 0.0f);
+    if (n == 0) return PBRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return log_enqueue(ctx, n, (const float *)d_env, dynamic_range_db, (float *)d_out);
 }
 
 int pbrt_log_compress(pbrt_ctx *ctx, uint32_t n, const float *env, float dynamic_range_db, float *out) {
     if (!ctx) return PBRT_E_INVALID;
     NEED(ctx, env && out && dynamic_range_db > 0.0f);
     LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
+    (void)grid;
+    (void)block;
+    (void)st;
     float *din = S.in(env, n), *dout = S.out<float>(n);
-    uint32_t *mx = S.out<uint32_t>(1);
-    HIPCHK(c, hipMemsetAsync(mx, 0, 4, st));
-    hipLaunchKernelGGL(k_env_max, dim3(std::min<uint32_t>(div_up(n, 256), 1024)), block, 0, st, n, din, mx);
-    hipLaunchKernelGGL(k_log_compress, grid, block, 0, st, n, din, mx, dynamic_range_db, dout);
+    int rc = log_enqueue(c, n, din, dynamic_range_db, dout);
+    if (rc) return rc;
     S.back(out, dout, n);
     return S.finish();
+}
+
+int pbrt_us_apply_pulse_dev(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
+                            const void *d_in, void *d_out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, d_in && d_out && d_in != d_out);
+    uint32_t K = 0;
+    int rc = pulse_check(ctx, n_traces, time_samples, fs, frequency, sigma, &K);
+    if (rc) return rc;
+    if (n_traces == 0 || time_samples == 0) return PBRT_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return pulse_enqueue(ctx, n_traces, time_samples, K, fs, frequency, sigma, (const float *)d_in, (float *)d_out);
 }
 
 int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples, float fs, float frequency, float sigma,
                         const float *in, float *out) {
     if (!ctx) return PBRT_E_INVALID;
-    NEED(ctx, in && out && in != out && fs > 0.0f && frequency > 0.0f && sigma > 0.0f);
-    NEED(ctx, (uint64_t)n_traces * time_samples < 0xffffffffull && n_traces <= 65535u);
-    const uint32_t K = (uint32_t)std::ceil(2.5 * (double)sigma * (double)fs);
-    NEED(ctx, K <= PULSE_MAX_K);
+    NEED(ctx, in && out && in != out);
+    uint32_t K = 0;
+    int rc = pulse_check(ctx, n_traces, time_samples, fs, frequency, sigma, &K);
+    if (rc) return rc;
     const uint32_t n = n_traces * time_samples;
     LEAF_BEGIN(ctx, (size_t)n * 8 + 64);
-    float *din = S.in(in, n), *dout = S.out<float>(n);
-    const size_t lds = (size_t)(2 * K + 1 + 256 + 2 * K) * 4;
     (void)grid;
-    hipLaunchKernelGGL(k_apply_pulse, dim3(div_up(time_samples, 256), n_traces), block, lds, st, time_samples, K, fs, frequency,
-                       sigma, din, dout);
+    (void)block;
+    (void)st;
+    float *din = S.in(in, n), *dout = S.out<float>(n);
+    if ((rc = pulse_enqueue(c, n_traces, time_samples, K, fs, frequency, sigma, din, dout)) != 0) return rc;
     S.back(out, dout, n);
     return S.finish();
+}
+
+// ---- device buffers and the stream (ABI 5): what a caller needs to keep the us_render loop in HBM without another GPU library ----
+int pbrt_ctx_synchronize(pbrt_ctx *c) {
+    if (!c) return PBRT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PBRT_OK;
+}
+
+int pbrt_ctx_set_profiling(pbrt_ctx *c, int on) {
+    if (!c) return PBRT_E_INVALID;
+    c->profiling = on != 0;
+    c->img_mask = 0;
+    return PBRT_OK;
+}
+
+int pbrt_get_image_stats(pbrt_ctx *c, pbrt_image_stats *out) {
+    if (!c || !out) return PBRT_E_INVALID;
+    std::memset(out, 0, sizeof *out);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double *slot[IMG_STEPS] = {&out->pulse_ms, &out->das_ms, &out->envelope_ms, &out->log_ms};
+    for (int i = 0; i < IMG_STEPS; ++i) {
+        if (!(c->img_mask & (1u << i))) continue;
+        float t = 0.0f;
+        HIPCHK(c, hipEventElapsedTime(&t, c->img_ev[2 * i], c->img_ev[2 * i + 1]));
+        *slot[i] = t;
+    }
+    out->das_model_bytes = c->img_das_bytes;
+    out->measured = c->img_mask;
+    return PBRT_OK;
+}
+
+int pbrt_dev_alloc(pbrt_ctx *c, uint64_t bytes, void **out) {
+    if (!c || !out) return PBRT_E_INVALID;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)std::max<uint64_t>(bytes, 16));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return c->fail(PBRT_E_NOMEM, "pbrt_dev_alloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    }
+    *out = p;
+    return PBRT_OK;
+}
+
+int pbrt_dev_free(pbrt_ctx *c, void *p) {
+    if (!c) return PBRT_E_INVALID;
+    if (!p) return PBRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // queued work may still read or write it
+    HIPCHK(c, hipFree(p));
+    return PBRT_OK;
+}
+
+int pbrt_dev_upload(pbrt_ctx *c, void *dst_dev, const void *src_host, uint64_t bytes) {
+    if (!c) return PBRT_E_INVALID;
+    NEED(c, (dst_dev && src_host) || bytes == 0);
+    if (!bytes) return PBRT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    // in stream order behind the queued kernels; a pageable source is staged before the call returns, so the caller may reuse it
+    HIPCHK(c, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    return PBRT_OK;
+}
+
+int pbrt_dev_download(pbrt_ctx *c, void *dst_host, const void *src_dev, uint64_t bytes) {
+    if (!c) return PBRT_E_INVALID;
+    NEED(c, (dst_host && src_dev) || bytes == 0);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return PBRT_OK;
 }
 
 }  // extern "C"

@@ -42,12 +42,13 @@ def _dist():
 
 
 def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=None, device=None, sample_offset=0,
-                 on_call=None, tile=None):
+                 on_call=None, tile=None, pass_paths=0):
     """Render this rank's bands into one [rows_max, W, 3] float32 torch tensor (padded to the largest
     rank).  render_band(crop, out_rows_tensor) fills a [rows, W, 3] view; the default calls the HIP
     library and writes straight into the tensor's device memory (no PCIe traffic).  on_call() runs after
     every library call (one per band; bench.py adds up the per-call statistics there).  tile: a tensor of a previous call
-    to render into again (every row of a rank's bands is overwritten)."""
+    to render into again (every row of a rank's bands is overwritten).  pass_paths: paths in flight per pass (0: the library's
+    default, which leaves half of the device to other tenants; a process that owns its GPU may ask for more)."""
     import torch
 
     sens = scene.sensors()[0]
@@ -68,7 +69,7 @@ def render_tiles(scene, spp, seed, rank, world_size, band_rows=64, render_band=N
             if dev.type != "cuda":
                 raise RuntimeError("the HIP render path needs a device tensor (torch 'cuda' == HIP on ROCm)")
             integ.render(scene, sensor=sens, seed=seed, spp=spp, crop=crop, sample_offset=sample_offset,
-                         out_dev=view.data_ptr())
+                         out_dev=view.data_ptr(), pass_paths=pass_paths)
             if on_call is not None:
                 on_call()
         off += rows

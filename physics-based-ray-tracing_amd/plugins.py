@@ -717,6 +717,24 @@ class UltraIntegrator(SamplingIntegrator):
             self.quirks |= _capi.USQ_NO_CARRIER
         self.max_path_len = 0.2  # CustomIntegrator.py:307,372
 
+    # channel_buf (CustomIntegrator.py:43,260; read at USMain.py:103): a host array, as in the reference.  When an acquisition
+    # left its result in HBM (us_render keeps the whole loop on the device) the copy to the host happens on first read.
+    @property
+    def channel_buf(self):
+        if self._channel_host is None and self._channel_dev is not None:
+            self._channel_host = self._channel_dev.numpy().reshape(self.n_angles, self.n_elements, self.time_samples)
+        return self._channel_host
+
+    @channel_buf.setter
+    def channel_buf(self, value):
+        self._channel_host = value
+        self._channel_dev = None
+
+    def _set_device_channel(self, dev_buffer):
+        """the channel buffer of the last acquisition sits in this DeviceBuffer; channel_buf fetches it when read"""
+        self._channel_host = None
+        self._channel_dev = dev_buffer
+
     def sample(self, scene, sampler, ray, medium=None, active=True):  # CustomIntegrator.py:52-53
         n = len(np.atleast_2d(np.asarray(ray["o"]))) if isinstance(ray, dict) else 1
         return np.zeros(n, np.float32), active, []

@@ -36,7 +36,8 @@ def test_struct_layouts_match_the_header(capi):
              "pbrt_scene_desc": C.sizeof(capi.SceneDesc), "pbrt_camera": C.sizeof(capi.Camera),
              "pbrt_film_desc": C.sizeof(capi.FilmDesc), "pbrt_us_params": C.sizeof(capi.UsParams),
              "pbrt_us_sensor": C.sizeof(capi.UsSensor), "pbrt_us_emitter": C.sizeof(capi.UsEmitter),
-             "pbrt_us_receiver": C.sizeof(capi.UsReceiver), "pbrt_stats": C.sizeof(capi.Stats)}
+             "pbrt_us_receiver": C.sizeof(capi.UsReceiver), "pbrt_stats": C.sizeof(capi.Stats),
+             "pbrt_das_params": C.sizeof(capi.DasParams), "pbrt_image_stats": C.sizeof(capi.ImageStats)}
     prog = '#include <stdio.h>\n#include "pbrt_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     exe = os.path.join(ROOT, "oracle", "_build", "abi_sizes")

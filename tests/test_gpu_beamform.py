@@ -161,3 +161,80 @@ def test_gaussian_pulse_acquisition_matches_the_oracle(mi, ob):
     assert np.linalg.norm(got - ref) <= 1e-3 * np.linalg.norm(ref) and np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max()
     # each echo now covers ~ wave_cycles * fs / f samples instead of one
     assert (got != 0).sum() > 5 * (ref_impulse != 0).sum()
+
+
+def test_device_resident_chain_equals_the_host_chain_bit_for_bit(mi):
+    """ABI 5: acquisition -> (pulse) -> DAS -> envelope -> log compression queued on the context's stream on device pointers, one
+    copy of the image to the host.  The channel buffer it ran on is then fetched and sent through the host-pointer entry points
+    (round 4's chain: every step up and down PCIe): same kernels on the same data, the images are equal bit for bit.  Round 4's
+    us_render itself (device_resident=False) runs its own acquisition, whose f32 atomics sum in another order: compared at the
+    acquisition's tolerance."""
+    for pulse in ("impulse", "gaussian"):
+        sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=32, seed=3)
+        ui = sc.integrator()
+        ui.pulse_model = pulse
+        if pulse == "gaussian":
+            ui.quirks |= mi._capi.USQ_NO_CARRIER
+        kw = dict(x_range=(-0.012, 0.012), z_range=(0.03, 0.07))
+        tm = {}
+        d_dev, b_dev, (xs, zs) = mi.us_render(sc, timing=tm, **kw)
+        assert ui._channel_host is None and ui._channel_dev is not None        # nothing but the two images crossed PCIe
+        assert d_dev.shape == (len(zs), len(xs)) and b_dev.shape == (len(xs), len(zs))
+        assert set(tm) == {"acquire", "queue", "wait_copy"} and all(v >= 0 for v in tm.values())
+        chan = ui.channel_buf                                                   # the lazy copy happens here
+        assert chan.shape == (5, 64, 10000) and ui._channel_host is not None and np.abs(chan).max() > 0
+        probe = mi.build_probe("linear", 64, ui.pitch, ui.frequency, 70)
+        rf = mi.das_beamform(chan, ui.transmission_delays_buf.reshape(5, 64), probe.geometry[0], xs, zs, ui.fs, ui.sound_speed)
+        env = mi.envelope(rf)
+        img = mi.log_compress(env, 60.0)
+        assert np.array_equal(env, b_dev) and np.array_equal(img.T, d_dev)
+        if pulse == "gaussian":                                                 # the buffer the images were formed from carries the pulse
+            bare = ui._acquire(sc, ui.quirks, pulse=False)
+            assert np.allclose(chan, mi.apply_pulse(bare, ui.fs, ui.frequency, ui.pulse_sigma), rtol=0, atol=2e-5 * np.abs(chan).max())
+        d_host, b_host, _ = mi.us_render(sc, device_resident=False, **kw)
+        assert np.allclose(b_host, b_dev, rtol=0, atol=2e-5 * b_dev.max())
+        d_only, none, _ = mi.us_render(sc, return_bmode=False, **kw)
+        assert none is None and d_only.shape == d_dev.shape and np.abs(d_only - d_dev).max() < 1e-3
+
+
+def test_image_formation_on_device_buffers_step_by_step(mi):
+    """each *_dev entry point against its host-pointer form on the same data (bit for bit), chained without a synchronisation in
+    between; per-step device times come back when profiling is on"""
+    cx = mi.default_context()
+    data, tx, ex, c, fs = _rand_case(21, 5, 64, 4000, c=1540.0, fs=50e6, pitch=1.2e-4)
+    lam = 1540.0 / 5e6
+    x = np.arange(-0.01, 0.01 + lam / 4, lam / 4)
+    z = np.arange(0.001, 0.03 + lam / 4, lam / 4)
+    for interp, fnum, comp in (("linear", 1.0, "sum"), ("nearest", 0.0, "mean")):
+        ref_bf = mi.das_beamform(data, tx, ex, x, z, fs, c, f_number=fnum, interpolation=interp, compound=comp)
+        ref_env = mi.envelope(ref_bf)
+        ref_img = mi.log_compress(ref_env, 50.0)
+        cx.set_profiling(True)
+        d_data = mi.DeviceBuffer.from_host(cx, data)
+        d_bf = mi.das_beamform(d_data, tx, ex, x, z, fs, c, f_number=fnum, interpolation=interp, compound=comp)
+        d_env = mi.envelope(d_bf)
+        d_img = mi.log_compress(d_env, 50.0)
+        assert isinstance(d_img, mi.DeviceBuffer) and d_img.shape == (len(x), len(z))
+        img = d_img.numpy()                                                     # the first wait
+        st = cx.image_stats()
+        cx.set_profiling(False)
+        assert np.array_equal(d_bf.numpy(), ref_bf) and np.array_equal(d_env.numpy(), ref_env) and np.array_equal(img, ref_img)
+        assert st["measured"] & 0b1110 == 0b1110 and 0 < st["das_ms"] < 50 and 0 < st["envelope_ms"] < 50 and 0 < st["log_ms"] < 50
+        assert st["das_model_bytes"] == (data.size + len(x) * len(z)) * 4
+    pulsed = mi.apply_pulse(d_data, fs, 5e6, 5 / (4 * 5e6))
+    assert np.array_equal(pulsed.numpy(), mi.apply_pulse(data, fs, 5e6, 5 / (4 * 5e6)))
+    with pytest.raises(RuntimeError):
+        mi.envelope(mi.DeviceBuffer(cx, (2, 5000)))                              # nz > 4096: error code from the *_dev form too
+    with pytest.raises(RuntimeError):
+        mi.apply_pulse(d_data, fs, 5e6, 5 / (4 * 5e6), out=d_data)               # in place is refused
+
+
+def test_envelope_of_odd_and_even_columns_against_scipy_definition(mi):
+    """the circular-convolution form of the analytic signal (round 5) at sizes around the tap-window edges: N = 1..9, 637 (the
+    lambda / 4 grid of USMain.py at 5 MHz), 4095, 4096"""
+    for N in list(range(1, 10)) + [637, 638, 4095, 4096]:
+        rng = np.random.default_rng(100 + N)
+        rf = rng.normal(size=(3, N)).astype(np.float32)
+        ref = obf.envelope(rf)
+        got = mi.envelope(rf)
+        assert np.allclose(got, ref, rtol=0, atol=2e-4 * max(ref.max(), 1e-6)), N

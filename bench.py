@@ -12,7 +12,9 @@ N > 1            BASELINE config 5: the same scene at 4096 x 4096, 1024 spp (17.
                  timed region; value = total samples / max-over-ranks time.  `--gpus N` without a torchrun environment
                  launches the ranks itself (python -m torch.distributed.run ..., as fresh child processes; the parent
                  never touches the GPU) and relays rank 0's JSON line.
---config NAME    cbox (config 2) | cbox4k (config 5) | us_testring (the ring of config 4 as ultrasound phantom) | us_sphere_box (config 3: MitsubaScenes/Sphere_Box.xml phantom,
+--config NAME    cbox (config 2) | cbox4k (config 5) | us_testring (the ring of config 4 as ultrasound phantom) | usmain_loop (one finite-difference
+                 iteration of the reference's optimisation loop, USMain.py:262-289: 2 x us_render, device-resident) | us_sphere_box_emitter
+                 (config 3 with every path's primary ray drawn from CustomEmitter.sample_ray) | us_sphere_box (config 3: MitsubaScenes/Sphere_Box.xml phantom,
                  5 x 64 rays x 838 912 paths = 268 M transducer paths, ultrasound mode; N > 1: path ranges + one
                  reduce(sum)) | testring (config 4: TestRing/TestRing.obj, 1024 x 1024, 512 spp, LDS-resident BVH;
                  N > 1: bands + gather).  Default: cbox at N = 1, cbox4k at N > 1.
@@ -78,6 +80,12 @@ CONFIGS = {
     "usmain_loop": dict(kind="usmain_loop", scene="us_plate.xml", ppr=(1, 64, 4096), baseline_config=None,
                         metric="ms per finite-difference iteration of USMain.py:262-289 (2 x us_render + 2 x params.update) at paths_per_ray 1",
                         what="USMain.py:26-90 plate + wall, 5 angles x 64 elements, channel buffer 5 x 64 x 10000, lambda / 4 scan grid"),
+    # BASELINE config 3 read literally ("Sphere_Box.xml with CustomBSDF + CustomEmmitter"): every path draws its primary ray from
+    # CustomEmitter.sample_ray (PBRT_US_PRIMARY_EMITTER, DESIGN D15) -- no first-bounce tables, bounce 0 traced by all 268 M paths
+    "us_sphere_box_emitter": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,
+                                  load=dict(primary_rays="emitter", paths_per_ray=838912),
+                                  metric="Msamples/s on MitsubaScenes/Sphere_Box.xml phantom with CustomEmitter primary rays, 5 x 64 rays x 838912 paths (ultrasound, UltraBSDF, max_depth 10)",
+                                  what="sphere + 5 walls, UltraBSDF, primary rays from CustomEmitter.sample_ray (64 elements, +-15 degrees in 5 strata), channel buffer 5 x 64 x 10000"),
     "us_sphere_box": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,
                           metric="Msamples/s on MitsubaScenes/Sphere_Box.xml phantom, 5 x 64 rays x 838912 paths (ultrasound, UltraBSDF, max_depth 10)",
                           what="sphere + 5 walls, UltraBSDF, 5 angles x 64 elements, channel buffer 5 x 64 x 10000"),
@@ -230,7 +238,7 @@ def main():
     if rank == 0 and world == 1 and args.config is None and not overridden and not args.no_also:
         # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line
         out["also"] = []
-        for other in ("us_sphere_box", "testring", "us_testring", "cbox4k"):
+        for other in ("us_sphere_box", "us_sphere_box_emitter", "testring", "us_testring", "cbox4k"):
             o = measure(env, other, dict(CONFIGS[other]), 3, 1, seed=0, overridden=False, with_cpu=not args.no_cpu_baseline,
                         cpu_seconds=min(args.cpu_seconds, 6.0))
             keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline", "l2_vs_cpu_ref", "cpu_baseline", "config")
@@ -286,7 +294,7 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         total_units = RES * RES * SPP
     else:
         PPR = cfg["ppr"]
-        scene = mi.load_file(os.path.join(SCENES, cfg["scene"]))
+        scene = mi.load_file(os.path.join(SCENES, cfg["scene"]), **cfg.get("load", {}))
         ui = scene.integrator()
         band_rows = 0
         total_units = ui.n_angles * ui.n_elements * PPR

@@ -189,6 +189,35 @@ typedef struct pbrt_film_desc {
  * the integrator reads from scene.sensors()[0].transform (CustomIntegrator.py:272). */
 #define PBRT_US_MAX_ANGLES 64
 
+/* CustomEmitter (CustomEmmitter.py:5-49), linear or convex array. */
+typedef struct pbrt_us_emitter {
+    uint32_t number_of_elements;
+    float pitch, element_width, element_height;
+    float radius;        /* 0: linear */
+    float opening_angle; /* degrees   */
+    uint32_t number_of_rays_per_element;
+    float speed_of_sound;
+    float steering_angle_min, steering_angle_max; /* degrees */
+} pbrt_us_emitter;
+
+/* Where the primary ray of a path comes from (pbrt_us_params.primary).
+ * ELEMENT  the integrator's own deterministic ray, CustomIntegrator.py:264-273: origin T (x_e, 0, 0), direction
+ *          normalize(T (sin theta_a, 0, cos theta_a)), emission time tx_delay[a, e], amplitude 1.  All paths of an (angle, element)
+ *          pair share it (which is what the first-bounce tables exploit).
+ * EMITTER  every path draws its own ray from CustomEmitter.sample_ray (CustomEmmitter.py:81-107, pbrt_us_params.emitter) -- what
+ *          BASELINE config 3 "with CustomBSDF + CustomEmmitter" means read literally.  The reference never connects the two classes
+ *          (its integrator does not call the emitter), so the connection is a definition of this library: the
+ *          (angle, element) grid of the acquisition stratifies the emitter's sample space -- path k of pair (a, e) calls
+ *              sample_ray(time = 0, sample1 = (e + 1/2) / N, sample2 = (u.x, u.y), sample3 = (a + u.z) / n_angles)
+ *          with u = the path's RNG block 0x80000000, i.e. element e (jittered inside the element by sample2, :64-68) and a steering
+ *          angle drawn uniformly from the a-th of n_angles equal parts of [steering_angle_min, steering_angle_max] (:85-87); the
+ *          ray is taken to the world with the sensor transform like the integrator's own (:272-273), its `time` (the element's
+ *          steering delay -x sin(psi) / c, :93-94) is the path's initial time of flight (t0 of :329 is then 0) and its weight
+ *          max(0, d.n) / N_total_rays (:97-98) the path's initial amplitude (:276 has 1).  emitter.number_of_elements must equal
+ *          n_elements.  No first-bounce tables: every path walks the scene from its own origin. */
+#define PBRT_US_PRIMARY_ELEMENT 0u
+#define PBRT_US_PRIMARY_EMITTER 1u
+
 typedef struct pbrt_us_params {
     uint32_t max_depth;    /* CustomIntegrator.py:16 */
     float frequency;       /* :17 */
@@ -205,6 +234,8 @@ typedef struct pbrt_us_params {
     float sensor_to_world[12]; /* row-major 3x4 */
     float max_path_len;        /* hard-coded 0.2 in the reference (:307,372) */
     uint32_t quirks;           /* PBRT_USQ_* */
+    uint32_t primary;          /* PBRT_US_PRIMARY_* (ABI 5) */
+    pbrt_us_emitter emitter;   /* read when primary == PBRT_US_PRIMARY_EMITTER */
 } pbrt_us_params;
 
 /* Behaviour switches; each bit reproduces one reference quirk.
@@ -244,17 +275,6 @@ typedef struct pbrt_us_sensor {
     float center_frequency, sound_speed, directivity;
     float to_world[12];
 } pbrt_us_sensor;
-
-/* CustomEmitter (CustomEmmitter.py:5-49), linear or convex array. */
-typedef struct pbrt_us_emitter {
-    uint32_t number_of_elements;
-    float pitch, element_width, element_height;
-    float radius;        /* 0: linear */
-    float opening_angle; /* degrees   */
-    uint32_t number_of_rays_per_element;
-    float speed_of_sound;
-    float steering_angle_min, steering_angle_max; /* degrees */
-} pbrt_us_emitter;
 
 /* CustomSensor.put_data accumulator (CustomSensor.py:7-59). */
 typedef struct pbrt_us_receiver {

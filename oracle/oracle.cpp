@@ -1116,6 +1116,44 @@ static inline float us_elem_x(const pbrt_us_params *p, uint32_t e) {
     return (float)((double)p->pitch * ((double)(float)e - ((double)p->n_elements - 1.0) / 2.0));
 }
 
+// One ray of CustomEmitter.sample_ray (CustomEmmitter.py:51-107): element pick (:56-57), element centre and normal of the linear
+// (:33-38) or convex (:41-47) array, jitter inside the element (:64-68), steering angle (:85-87), direction (:90), steering delay
+// (:93-94), cosine weight (:97-98).  Shared by the leaf operator and by the acquisition's emitter-primary mode.
+struct EmitRay {
+    V3 o, d;
+    float time, weight, pdf_pos;
+};
+static inline EmitRay emitter_ray(const pbrt_us_emitter &e, float time, float s1, float s2x, float s2y, float s3) {
+    const float N = (float)e.number_of_elements;
+    const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
+    float idx = fminf(floorf(s1 * N), N - 1.0f);                                            // :56-57
+    V3 c, nrm;
+    if (e.radius == 0.0f) {                                                                 // :33-38 linspace
+        float lo = -(N - 1.0f) / 2.0f * e.pitch, hi = (N - 1.0f) / 2.0f * e.pitch;
+        float x = N > 1.0f ? fmaf(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {x, 0.0f, 0.0f};
+        nrm = {0.0f, 0.0f, 1.0f};
+    } else {                                                                                // :41-47
+        float span = e.opening_angle * (kPi / 180.0f);
+        float lo = -span / 2.0f, hi = span / 2.0f;
+        float th = N > 1.0f ? fmaf(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
+        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
+    }
+    float dx = (s2x - 0.5f) * e.element_width, dy = (s2y - 0.5f) * e.element_height;        // :64-65
+    EmitRay r;
+    r.o = c + v3(dx, dy, 0.0f);                                                             // :68
+    r.pdf_pos = 1.0f / (N * e.element_width * e.element_height);                            // :77
+    float pmin = e.steering_angle_min * (kPi / 180.0f), pmax = e.steering_angle_max * (kPi / 180.0f);
+    float psi = fmaf(s3, pmax - pmin, pmin);                                                // :85-87
+    r.d = {sinf(psi), 0.0f, cosf(psi)};                                                     // :90
+    float delay = -(r.o.x * sinf(psi)) / e.speed_of_sound;                                  // :93
+    r.time = time + delay;                                                                  // :94
+    float fd = fmaxf(0.0f, dot(r.d, nrm));                                                  // :97
+    r.weight = fd / total_rays;                                                             // :98
+    return r;
+}
+
 static inline float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // :289-304
     V3 w = -sec_dir;
     float dt = dot(tn, w);
@@ -1141,18 +1179,33 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
     const float two_pi_f = (float)(2.0 * M_PI * (double)p->frequency);                         // :330
     const float inv_c = 1.0f / p->sound_speed;
     uint64_t segs = 0, shadows = 0;
+    const bool emit = p->primary == PBRT_US_PRIMARY_EMITTER;
+    if (emit && p->emitter.number_of_elements != NE) return PBRT_E_INVALID;
     for (uint32_t a = 0; a < NA; ++a)
         for (uint32_t e = 0; e < NE; ++e) {
             const uint32_t ray_id = a * NE + e;
             const float a_rad = (float)((double)p->angles_deg[a] * (M_PI / 180.0));
             const float x_elem = us_elem_x(p, e);
-            const float t0 = tx[ray_id];                                                       // :267
+            const float t0_elem = tx[ray_id];                                                  // :267
             const V3 o0 = xf_point(p->sensor_to_world, v3(x_elem, 0, 0));                      // :270,273
             const V3 d0 = normalize(xf_vec(p->sensor_to_world, v3(sinf(a_rad), 0.0f, cosf(a_rad))));  // :271,273
             for (uint32_t kk = 0; kk < paths_per_ray; ++kk) {
                 const uint32_t k = path_offset + kk;
                 V3 o = o0, d = d0;
                 float amp = 1.0f, atten = 1.0f, tof = 0.0f, geo_len = 0.0f;                    // :276-279
+                float t0 = t0_elem;
+                if (emit) {
+                    // PBRT_US_PRIMARY_EMITTER (include/pbrt_hip.h, DESIGN D15): the path's own ray from CustomEmitter.sample_ray,
+                    // the (angle, element) grid stratifying the emitter's element pick and steering angle; RNG block 0x80000000
+                    const F4 ue = rng4(ray_id, k, 0x80000000u, seed);
+                    const float s1 = ((float)e + 0.5f) / (float)NE, s3 = ((float)a + ue.z) / (float)NA;
+                    const EmitRay r = emitter_ray(p->emitter, 0.0f, s1, ue.x, ue.y, s3);       // CustomEmmitter.py:81-107
+                    o = xf_point(p->sensor_to_world, r.o);                                     // (:272-273 for the integrator's own ray)
+                    d = normalize(xf_vec(p->sensor_to_world, r.d));
+                    amp = r.weight;                                                            // CustomEmmitter.py:97-98
+                    tof = r.time;                                                              // :93-94: the steering delay starts the clock
+                    t0 = 0.0f;
+                }
                 uint32_t depth = 0;
                 bool active = true;
                 while (active && depth < p->max_depth && geo_len < p->max_path_len) {          // :307
@@ -1355,35 +1408,13 @@ int oracle_us_sensor_sample_ray(const pbrt_us_sensor *s, int use_hemisphere_warp
 int oracle_us_emitter_sample_ray(const pbrt_us_emitter *e, uint32_t n, const float *time, const float *s1,
                                  const float *s2, const float *s3, float *o, float *d, float *ray_time, float *weight,
                                  float *pdf_pos) {
-    const float N = (float)e->number_of_elements;
-    const float total_rays = (float)(e->number_of_elements * e->number_of_rays_per_element);  // :17
     for (uint32_t i = 0; i < n; ++i) {
-        float idx = fminf(floorf(s1[i] * N), N - 1.0f);                                       // :56-57
-        V3 c, nrm;
-        if (e->radius == 0.0f) {                                                              // :33-38 linspace
-            float lo = -(N - 1.0f) / 2.0f * e->pitch, hi = (N - 1.0f) / 2.0f * e->pitch;
-            float x = N > 1.0f ? fmaf(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-            c = {x, 0.0f, 0.0f};
-            nrm = {0.0f, 0.0f, 1.0f};
-        } else {                                                                              // :41-47
-            float span = e->opening_angle * (kPi / 180.0f);
-            float lo = -span / 2.0f, hi = span / 2.0f;
-            float th = N > 1.0f ? fmaf(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-            c = {e->radius * sinf(th), 0.0f, e->radius * cosf(th)};
-            nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                    // :49
-        }
-        float dx = (s2[i] - 0.5f) * e->element_width, dy = (s2[n + i] - 0.5f) * e->element_height;  // :64-65
-        V3 pos = c + v3(dx, dy, 0.0f);                                                        // :68
-        pdf_pos[i] = 1.0f / (N * e->element_width * e->element_height);                       // :77
-        float pmin = e->steering_angle_min * (kPi / 180.0f), pmax = e->steering_angle_max * (kPi / 180.0f);
-        float psi = fmaf(s3[i], pmax - pmin, pmin);                                           // :85-87
-        V3 dir = {sinf(psi), 0.0f, cosf(psi)};                                                // :90
-        float delay = -(pos.x * sinf(psi)) / e->speed_of_sound;                               // :93
-        ray_time[i] = time[i] + delay;                                                        // :94
-        float fd = fmaxf(0.0f, dot(dir, nrm));                                                // :97
-        weight[i] = fd / total_rays;                                                          // :98
-        o[i] = pos.x; o[n + i] = pos.y; o[2 * n + i] = pos.z;
-        d[i] = dir.x; d[n + i] = dir.y; d[2 * n + i] = dir.z;
+        const EmitRay r = emitter_ray(*e, time[i], s1[i], s2[i], s2[n + i], s3[i]);
+        pdf_pos[i] = r.pdf_pos;
+        ray_time[i] = r.time;
+        weight[i] = r.weight;
+        o[i] = r.o.x; o[n + i] = r.o.y; o[2 * n + i] = r.o.z;
+        d[i] = r.d.x; d[n + i] = r.d.y; d[2 * n + i] = r.d.z;
     }
     return PBRT_OK;
 }

@@ -97,25 +97,29 @@ class FilmDesc(C.Structure):
                 ("pass_paths", C.c_uint32)]
 
 
+class UsEmitter(C.Structure):
+    _fields_ = [("number_of_elements", C.c_uint32), ("pitch", C.c_float), ("element_width", C.c_float),
+                ("element_height", C.c_float), ("radius", C.c_float), ("opening_angle", C.c_float),
+                ("number_of_rays_per_element", C.c_uint32), ("speed_of_sound", C.c_float),
+                ("steering_angle_min", C.c_float), ("steering_angle_max", C.c_float)]
+
+
 class UsParams(C.Structure):
     _fields_ = [("max_depth", C.c_uint32), ("frequency", C.c_float), ("sound_speed", C.c_float),
                 ("attenuation", C.c_float), ("main_beam_angle", C.c_float), ("cutoff_angle", C.c_float),
                 ("fs", C.c_float), ("n_elements", C.c_uint32), ("pitch", C.c_float), ("n_angles", C.c_uint32),
                 ("angles_deg", C.c_float * US_MAX_ANGLES), ("time_samples", C.c_uint32),
-                ("sensor_to_world", C.c_float * 12), ("max_path_len", C.c_float), ("quirks", C.c_uint32)]
+                ("sensor_to_world", C.c_float * 12), ("max_path_len", C.c_float), ("quirks", C.c_uint32),
+                ("primary", C.c_uint32), ("emitter", UsEmitter)]
+
+
+US_PRIMARY_ELEMENT, US_PRIMARY_EMITTER = 0, 1
 
 
 class UsSensor(C.Structure):
     _fields_ = [("num_elements", C.c_uint32), ("element_width", C.c_float), ("element_height", C.c_float),
                 ("pitch", C.c_float), ("radius", C.c_float), ("center_frequency", C.c_float),
                 ("sound_speed", C.c_float), ("directivity", C.c_float), ("to_world", C.c_float * 12)]
-
-
-class UsEmitter(C.Structure):
-    _fields_ = [("number_of_elements", C.c_uint32), ("pitch", C.c_float), ("element_width", C.c_float),
-                ("element_height", C.c_float), ("radius", C.c_float), ("opening_angle", C.c_float),
-                ("number_of_rays_per_element", C.c_uint32), ("speed_of_sound", C.c_float),
-                ("steering_angle_min", C.c_float), ("steering_angle_max", C.c_float)]
 
 
 class UsReceiver(C.Structure):

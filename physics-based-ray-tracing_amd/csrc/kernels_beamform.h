@@ -20,76 +20,220 @@
 //    all of those angles from one distance -- 64 + |aperture| square roots per pixel and trip instead of 128 per angle;
 //  * with the f-number aperture most of a lambda / 4 scan (USMain.py:180-194: +-40 mm for a 7.7 mm array) lies outside every
 //    element's cone: a tile whose pixels see no element writes its zeros and leaves before the first square root;
+//  * the elements of a tile are dealt to the DAS_SPLIT waves of its workgroup (element e to wave e % 4): each keeps the running
+//    minimum over its share, the shares meet in LDS, each gathers for its share of the aperture and the partial sums are added in
+//    wave order.  The first form (one wave per tile) spent 7 600 VALU instructions per tile in ONE dependent f64 stream with
+//    ~4 such waves per SIMD: 148 us with the VALUs 40 % busy; four times as many waves, each a quarter as long, fill the SIMDs;
+//  * a sample position is kept as whole samples + an f32 fraction (DasPos): per (element, angle) an integer add, an f32 add and
+//    the carry instead of five f64 instructions;
 //  * element positions and transmit delays are read with a wave-uniform index (scalar loads), the interpolation mode is a
 //    template parameter.
-// Sample positions in f64 as before (a position of 10^4 samples leaves f32 only 10 bits of fraction; parity with
-// oracle/beamform.py holds at the tolerances of tests/test_gpu_beamform.py), samples and sums in f32; the order of the sum is
-// now (trip of angles, element, angle) instead of (angle, element).
-#define DAS_ANG 8
-#define DAS_TILE 16  // pixels per workgroup edge: 2 x 2 waves of 8 x 8
+// Sample positions are still evaluated in f64 (a position of 10^4 samples leaves f32 only 10 bits of fraction; parity with
+// oracle/beamform.py holds at the tolerances of tests/test_gpu_beamform.py) and only then split; samples and sums in f32; the
+// order of the sum is (wave = e % 4, trip of angles, element, angle) instead of (angle, element).
+#ifndef DAS_ANG
+#define DAS_ANG 5  // angles per trip: 4 / 5 / 8 -> 180 / 142 / 162 us at the 5 angles of USMain.py (64 / 70 / 88 VGPRs; 4 needs two trips)
+#endif
+#ifndef DAS_SPLIT
+#define DAS_SPLIT 4  // waves that share the elements of one tile (1, 2 or 4)
+#endif
+#define DAS_TILE 8u
+#define DAS_XCDS 8u
+#define DAS_BANDS (2u * DAS_XCDS)
+
+// Which tile does workgroup b take?  Workgroup b runs on XCD b % 8, and every XCD has its own 4 MB L2: the z-tiles are cut into 16
+// bands and XCD k takes the bands k and 15 - k -- an XCD then reads one eighth of the samples (a pixel at depth z reads around
+// sample 2 z fs / c), and, the receive cone widening linearly with depth, a shallow band and its deep mirror together always hold
+// the same number of pixels that see an element: the same work on every XCD.  (Measured neutral at the sizes of USMain.py, 151
+// against 148 us: the 4.2 MB that are read at all stay cached either way; kept for larger acquisitions.)
+// -> (tx, tz), or false for a slot beyond the XCD's share.  m = z-tiles of the largest share.
+struct DasGrid {
+    uint32_t ntx, ntz, m;
+};
+DEV uint32_t das_band_lo(uint32_t band, uint32_t ntz) { return (band * ntz + DAS_BANDS - 1u) / DAS_BANDS; }
+DEV bool das_tile_of(const DasGrid g, uint32_t b, uint32_t *tx, uint32_t *tz) {
+#ifdef DAS_NO_XCD_BANDS
+    *tx = b / g.ntz;
+    *tz = b - *tx * g.ntz;
+    return *tx < g.ntx;
+#else
+    const uint32_t xcd = b % DAS_XCDS, i = b / DAS_XCDS;
+    const uint32_t lo1 = das_band_lo(xcd, g.ntz), n1 = das_band_lo(xcd + 1u, g.ntz) - lo1;
+    const uint32_t lo2 = das_band_lo(DAS_BANDS - 1u - xcd, g.ntz), n2 = das_band_lo(DAS_BANDS - xcd, g.ntz) - lo2;
+    const uint32_t t = i / g.m, r = i - t * g.m;
+    *tx = t;
+    *tz = r < n1 ? lo1 + r : lo2 + (r - n1);
+    return t < g.ntx && r < n1 + n2;
+#endif
+}
+
+// |(dx, z)|.  DAS_SQRT_NR: f32 v_rsq seed + two Goldschmidt steps + one Heron correction in f64 (< 1 ulp) instead of the compiler's
+// correctly rounded expansion around v_rsq_f64; arguments outside the f32 range (or 0) take the library routine.
+DEV double das_dist(double r) {
+#ifdef DAS_SQRT_NR
+    if (r > 1e-30 && r < 1e30) {
+        const double y = (double)__frsqrt_rn((float)r);
+        double g = r * y, h = 0.5 * y;
+        double e = __builtin_fma(-g, h, 0.5);
+        g = __builtin_fma(g, e, g);
+        h = __builtin_fma(h, e, h);
+        e = __builtin_fma(-g, h, 0.5);
+        g = __builtin_fma(g, e, g);
+        h = __builtin_fma(h, e, h);
+        return __builtin_fma(__builtin_fma(-g, g, r), h, g);
+    }
+#endif
+    return sqrt(r);
+}
+
+// A sample position as whole samples + a fraction in [0, 1): the sum of two positions is an integer add, an f32 add and the carry
+// (v_fract / v_floor) -- 2-cycle instructions -- where the f64 form needs add, multiply, floor / convert, subtract, convert at 4
+// cycles each per (element, angle).  The fraction keeps 24 bits (1.2e-7 samples; the f64 form rounds the interpolation weight
+// to f32 as well), the whole part is exact.
+struct DasPos {
+    int32_t i;
+    float f;
+};
+DEV DasPos das_split(double s) {
+    const double fl = floor(s);
+    DasPos p;
+    p.i = (int32_t)fl;  // saturates for positions beyond +-2^31 samples; the range test refuses those
+    p.f = (float)(s - fl);
+    if (p.f >= 1.0f) {  // s - floor(s) rounded up to 1
+        p.f = 0.0f;
+        p.i += 1;
+    }
+    return p;
+}
+
+// element e of a table whose entry l sits in lane l (e wave-uniform): two v_readlane, no memory access
+DEV double das_lane_f64(double v, uint32_t e) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, (int)e);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), (int)e);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 template <uint32_t INTERP>
-__global__ __launch_bounds__(256) void k_das_beamform(pbrt_das_params p, const float *__restrict__ data,
-                                                      const float *__restrict__ tx, const float *__restrict__ elem_x,
-                                                      const float *__restrict__ gx, const float *__restrict__ gz,
-                                                      float *__restrict__ out) {
+__global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params p, DasGrid grid, const float *__restrict__ data,
+                                                                 const float *__restrict__ tx, const float *__restrict__ elem_x,
+                                                                 const float *__restrict__ gx, const float *__restrict__ gz,
+                                                                 float *__restrict__ out) {
+    __shared__ double s_tmin[DAS_SPLIT][DAS_ANG][64];
+    __shared__ float s_acc[DAS_SPLIT][64];
+    uint32_t tile_x, tile_z;
+    if (!das_tile_of(grid, blockIdx.x, &tile_x, &tile_z)) return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t ix = blockIdx.y * DAS_TILE + (wave >> 1) * 8u + (lane >> 3);
-    const uint32_t iz = blockIdx.x * DAS_TILE + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t ix = tile_x * DAS_TILE + (lane >> 3), iz = tile_z * DAS_TILE + (lane & 7u);
     const bool valid = ix < p.nx && iz < p.nz;
     const double x = (double)gx[min(ix, p.nx - 1u)], z = (double)gz[min(iz, p.nz - 1u)];
     const double inv_c = 1.0 / (double)p.sound_speed, fs = (double)p.fs, t0 = (double)p.t0;
     const uint32_t A = p.n_angles, E = p.n_elements, T = p.time_samples;
     const double half_ap = p.f_number > 0.0f ? z / (2.0 * (double)p.f_number) : 1e300;
     const double zz = z * z;
-    // which pixels of the tile see an element at all?
+    // Element positions and transmit delays are tables of the launch, indexed by the (wave-uniform) element: as scalar loads they
+    // put a trip to the scalar cache (or to L2) in front of every element of every loop -- a wave alone on its CU took 100 us for
+    // 7 600 VALU instructions.  Instead lane l of the wave holds entry l of the current block of 64 elements, as doubles, and an
+    // element is picked with v_readlane: no memory access inside the loops at all.
+    // which pixels of the tile see an element at all?  (every wave of the workgroup finds the same answer)
     bool any = false;
-    for (uint32_t e = 0; e < E; ++e) any = any || (fabs(x - (double)elem_x[e]) <= half_ap);
+    for (uint32_t eb = 0; eb < E; eb += 64u) {
+        const uint32_t ne = min(64u, E - eb);
+        const double ex_l = (double)elem_x[eb + min(lane, ne - 1u)];
+        for (uint32_t e = 0; e < ne; ++e) any = any || (fabs(x - das_lane_f64(ex_l, e)) <= half_ap);
+    }
     any = any && valid;
     if (__ballot(any) == 0ull) {
-        if (valid) out[(size_t)ix * p.nz + iz] = 0.0f;
+        if (valid && wave == 0) out[(size_t)ix * p.nz + iz] = 0.0f;
         return;
     }
     float acc = 0.0f;
     const double last = (double)(T - 1u);
     for (uint32_t a0 = 0; a0 < A; a0 += DAS_ANG) {
         const uint32_t na = min((uint32_t)DAS_ANG, A - a0);
-        // first arrival of the emitted wavefront at the pixel, for the angles of this trip
+        // first arrival of the emitted wavefront at the pixel, for the angles of this trip: this wave's share of the elements ...
         double tmin[DAS_ANG];
 #pragma unroll
         for (uint32_t j = 0; j < DAS_ANG; ++j) tmin[j] = 1e300;
-        for (uint32_t e = 0; e < E; ++e) {
-            const double dx = x - (double)elem_x[e];
-            const double d = sqrt(dx * dx + zz) * inv_c;
+        for (uint32_t eb = 0; eb < E; eb += 64u) {
+            const uint32_t ne = min(64u, E - eb), le = min(lane, ne - 1u);
+            const double ex_l = (double)elem_x[eb + le];
+            double tx_l[DAS_ANG];
+#pragma unroll
+            for (uint32_t j = 0; j < DAS_ANG; ++j) tx_l[j] = j < na ? (double)tx[(size_t)(a0 + j) * E + eb + le] : 0.0;
+            for (uint32_t e = wave; e < ne; e += DAS_SPLIT) {
+                const double dx = x - das_lane_f64(ex_l, e);
+                const double d = das_dist(dx * dx + zz) * inv_c;
+#pragma unroll
+                for (uint32_t j = 0; j < DAS_ANG; ++j)
+                    if (j < na) tmin[j] = fmin(tmin[j], das_lane_f64(tx_l[j], e) + d);
+            }
+        }
+        // ... and the minimum over the waves
+        if (DAS_SPLIT > 1) {
+            if (a0) __syncthreads();  // the previous trip's table has been read
 #pragma unroll
             for (uint32_t j = 0; j < DAS_ANG; ++j)
-                if (j < na) tmin[j] = fmin(tmin[j], (double)tx[(size_t)(a0 + j) * E + e] + d);
-        }
-        for (uint32_t e = 0; e < E; ++e) {
-            const double dx = x - (double)elem_x[e];
-            const bool in_ap = any && fabs(dx) <= half_ap;
-            if (__ballot(in_ap) == 0ull) continue;
-            const double d = sqrt(dx * dx + zz) * inv_c - t0;
+                if (j < na) s_tmin[wave][j][lane] = tmin[j];
+            __syncthreads();
 #pragma unroll
             for (uint32_t j = 0; j < DAS_ANG; ++j) {
                 if (j >= na) break;
-                const float *trace = data + ((size_t)(a0 + j) * E + e) * T;
-                const double s = (tmin[j] + d) * fs;
+                double m = s_tmin[0][j][lane];
+                for (uint32_t w = 1; w < DAS_SPLIT; ++w) m = fmin(m, s_tmin[w][j][lane]);
+                tmin[j] = m;
+            }
+        }
+        DasPos tp[DAS_ANG];
+        if (INTERP == PBRT_DAS_LINEAR) {
+#pragma unroll
+            for (uint32_t j = 0; j < DAS_ANG; ++j)
+                if (j < na) tp[j] = das_split((tmin[j] - t0) * fs);
+        }
+        for (uint32_t eb = 0; eb < E; eb += 64u) {
+            const uint32_t ne = min(64u, E - eb);
+            const double ex_l = (double)elem_x[eb + min(lane, ne - 1u)];
+            for (uint32_t el = wave; el < ne; el += DAS_SPLIT) {
+                const uint32_t e = eb + el;
+                const double dx = x - das_lane_f64(ex_l, el);
+                const bool in_ap = any && fabs(dx) <= half_ap;
+                if (__ballot(in_ap) == 0ull) continue;
+                const double d = das_dist(dx * dx + zz) * inv_c;
                 if (INTERP == PBRT_DAS_NEAREST) {
-                    const double r = rint(s);
-                    if (in_ap && r >= 0.0 && r <= last) acc += trace[(uint32_t)r];
+#pragma unroll
+                    for (uint32_t j = 0; j < DAS_ANG; ++j) {
+                        if (j >= na) break;
+                        const float *trace = data + ((size_t)(a0 + j) * E + e) * T;
+                        const double r = rint((tmin[j] + d - t0) * fs);
+                        if (in_ap && r >= 0.0 && r <= last) acc += trace[(uint32_t)r];
+                    }
                 } else {
-                    const double f = floor(s);
-                    if (in_ap && f >= 0.0 && f < last) {
-                        const uint32_t i0 = (uint32_t)f;
-                        const float w = (float)(s - f);
-                        const float v0 = trace[i0], v1 = trace[i0 + 1];
-                        acc += fma_(w, v1 - v0, v0);
-                    } else if (in_ap && s == last) {
-                        acc += trace[T - 1u];
+                    const DasPos dp = das_split(d * fs);
+#pragma unroll
+                    for (uint32_t j = 0; j < DAS_ANG; ++j) {
+                        if (j >= na) break;
+                        const float *trace = data + ((size_t)(a0 + j) * E + e) * T;
+                        const float fr = tp[j].f + dp.f;  // [0, 2)
+                        const float fl = floorf(fr);
+                        const float w = fr - fl;
+                        const uint32_t i0 = (uint32_t)(tp[j].i + dp.i + (int32_t)fl);
+                        if (in_ap && i0 < T - 1u) {
+                            const float v0 = trace[i0], v1 = trace[i0 + 1];
+                            acc += fma_(w, v1 - v0, v0);
+                        } else if (in_ap && i0 == T - 1u && w == 0.0f) {  // exactly the last sample
+                            acc += trace[T - 1u];
+                        }
                     }
                 }
             }
         }
+    }
+    if (DAS_SPLIT > 1) {  // the waves' partial sums, added in wave order
+        s_acc[wave][lane] = acc;
+        __syncthreads();
+        if (wave != 0) return;
+        acc = s_acc[0][lane];
+        for (uint32_t w = 1; w < DAS_SPLIT; ++w) acc += s_acc[w][lane];
     }
     if (valid) out[(size_t)ix * p.nz + iz] = p.compound_mean ? acc / (float)A : acc;
 }

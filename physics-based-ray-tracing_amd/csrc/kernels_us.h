@@ -50,6 +50,60 @@ DEV float directivity_weight_i(V3 sec_dir, V3 tn, float am, float ac) {  // Cust
     return alpha <= am ? 1.0f : (alpha <= ac ? mid : 0.0f);
 }
 
+// One ray of CustomEmitter.sample_ray (CustomEmmitter.py:51-107): element pick (:56-57), element centre and normal of the linear
+// (:33-38) or convex (:41-47) array, jitter inside the element (:64-68), steering angle (:85-87), direction (:90), steering delay
+// (:93-94), cosine weight (:97-98).  Shared by the leaf operator and by the acquisition's emitter-primary mode.
+struct EmitRay {
+    V3 o, d;
+    float time, weight, pdf_pos;
+};
+DEV EmitRay us_emitter_ray(const pbrt_us_emitter &e, float time, float s1, float s2x, float s2y, float s3) {
+    const float N = (float)e.number_of_elements;
+    const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
+    float idx = fminf(floorf(s1 * N), N - 1.0f);                                            // :56-57
+    V3 c, nrm;
+    if (e.radius == 0.0f) {                                                                 // :33-38
+        float lo = -(N - 1.0f) / 2.0f * e.pitch, hi = (N - 1.0f) / 2.0f * e.pitch;
+        float x = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {x, 0.0f, 0.0f};
+        nrm = {0.0f, 0.0f, 1.0f};
+    } else {                                                                                // :41-47
+        float span = e.opening_angle * (K_PI / 180.0f);
+        float lo = -span / 2.0f, hi = span / 2.0f;
+        float th = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
+        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
+        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
+    }
+    float dx = (s2x - 0.5f) * e.element_width, dy = (s2y - 0.5f) * e.element_height;        // :64-65
+    EmitRay r;
+    r.o = c + v3(dx, dy, 0.0f);                                                             // :68
+    r.pdf_pos = 1.0f / (N * e.element_width * e.element_height);                            // :77
+    float pmin = e.steering_angle_min * (K_PI / 180.0f), pmax = e.steering_angle_max * (K_PI / 180.0f);
+    float psi = fma_(s3, pmax - pmin, pmin);                                                // :85-87
+    r.d = {sinf(psi), 0.0f, cosf(psi)};                                                     // :90
+    float delay = -(r.o.x * sinf(psi)) / e.speed_of_sound;                                  // :93
+    r.time = time + delay;                                                                  // :94
+    float fd = fmaxf(0.0f, dot(r.d, nrm));                                                  // :97
+    r.weight = fd / total_rays;                                                             // :98
+    return r;
+}
+
+// PBRT_US_PRIMARY_EMITTER (include/pbrt_hip.h, DESIGN D15): the primary ray of path k of the (angle, element) pair -- its own draw
+// from CustomEmitter.sample_ray, the acquisition grid stratifying the element pick and the steering angle, RNG block 0x80000000.
+// -> origin and direction in the world (the sensor transform, as :272-273 do for the integrator's own ray), the initial amplitude
+// (the emitter's weight) and the initial time of flight (the emitter's ray time: the element's steering delay).
+#define US_EMIT_BLOCK 0x80000000u
+DEV void us_emitter_primary(const pbrt_us_params &p, const float *M, uint32_t ray_id, uint32_t k, uint32_t ang, uint32_t el,
+                            uint32_t seed, V3 *o, V3 *d, float *amp, float *tof) {
+    const F4 ue = rng4(ray_id, k, US_EMIT_BLOCK, seed);
+    const float s1 = ((float)el + 0.5f) / (float)p.n_elements, s3 = ((float)ang + ue.z) / (float)p.n_angles;
+    const EmitRay r = us_emitter_ray(p.emitter, 0.0f, s1, ue.x, ue.y, s3);
+    *o = xf_point(M, r.o);
+    *d = normalize(xf_vec(M, r.d));
+    *amp = r.weight;
+    *tof = r.time;
+}
+
 // waves per SIMD the register allocator aims for: the ultrasound bounce (GGX sampling, expf / sinf / acosf) needs
 // about 95 VGPRs: 4 waves per SIMD run it without spills.  (While same-word global atomics dominated the kernel the
 // spilling 8-wave build was the fastest -- 2.83 / 2.98 / 3.06 ms at 8 / 6 / 4 waves; with the echoes summed in LDS
@@ -73,7 +127,9 @@ __host__ __device__ constexpr uint32_t us_owners_per_region(int accel) {
     return rad_wave_private(accel) ? seg_threads(accel) / 64 : 1;
 }
 
-template <bool FIRST, int ACCEL>
+// EMIT: the instance whose first bounce draws every path's primary ray from CustomEmitter.sample_ray (PBRT_US_PRIMARY_EMITTER); an
+// instance of its own so that the deterministic-ray kernels keep their register allocation (they sit at the 6-wave budget).
+template <bool FIRST, int ACCEL, bool EMIT = false>
 __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
@@ -188,6 +244,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             atten = 1.0f;
             tof = 0.0f;
             geo_len = 0.0f;                                                            // :276-279
+            if (EMIT) us_emitter_primary(a.p, U_M, ray_id, k, ang, el, a.seed, &o, &d, &amp, &tof);  // (a.tx is all zero then)
         } else {
             const uint32_t v4 = us_state_voff(slot);
             constexpr uint32_t row = STATE_ROW_BYTES;
@@ -602,38 +659,16 @@ __global__ __launch_bounds__(256) void k_us_emitter_sample_ray(pbrt_us_emitter e
                                                                float *d, float *ray_time, float *weight, float *pdf_pos) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float N = (float)e.number_of_elements;
-    const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
-    float idx = fminf(floorf(s1[i] * N), N - 1.0f);                                         // :56-57
-    V3 c, nrm;
-    if (e.radius == 0.0f) {                                                                 // :33-38
-        float lo = -(N - 1.0f) / 2.0f * e.pitch, hi = (N - 1.0f) / 2.0f * e.pitch;
-        float x = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-        c = {x, 0.0f, 0.0f};
-        nrm = {0.0f, 0.0f, 1.0f};
-    } else {                                                                                // :41-47
-        float span = e.opening_angle * (K_PI / 180.0f);
-        float lo = -span / 2.0f, hi = span / 2.0f;
-        float th = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
-        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
-    }
-    float dx = (s2[i] - 0.5f) * e.element_width, dy = (s2[n + i] - 0.5f) * e.element_height;  // :64-65
-    V3 pos = c + v3(dx, dy, 0.0f);                                                          // :68
-    pdf_pos[i] = 1.0f / (N * e.element_width * e.element_height);                           // :77
-    float pmin = e.steering_angle_min * (K_PI / 180.0f), pmax = e.steering_angle_max * (K_PI / 180.0f);
-    float psi = fma_(s3[i], pmax - pmin, pmin);                                             // :85-87
-    V3 dir = {sinf(psi), 0.0f, cosf(psi)};                                                  // :90
-    float delay = -(pos.x * sinf(psi)) / e.speed_of_sound;                                  // :93
-    ray_time[i] = time[i] + delay;                                                          // :94
-    float fd = fmaxf(0.0f, dot(dir, nrm));                                                  // :97
-    weight[i] = fd / total_rays;                                                            // :98
-    o[i] = pos.x;
-    o[n + i] = pos.y;
-    o[2 * n + i] = pos.z;
-    d[i] = dir.x;
-    d[n + i] = dir.y;
-    d[2 * n + i] = dir.z;
+    const EmitRay r = us_emitter_ray(e, time[i], s1[i], s2[i], s2[n + i], s3[i]);
+    pdf_pos[i] = r.pdf_pos;
+    ray_time[i] = r.time;
+    weight[i] = r.weight;
+    o[i] = r.o.x;
+    o[n + i] = r.o.y;
+    o[2 * n + i] = r.o.z;
+    d[i] = r.d.x;
+    d[n + i] = r.d.y;
+    d[2 * n + i] = r.d.z;
 }
 
 // CustomSensor.put_data (CustomSensor.py:29-59)

@@ -44,10 +44,13 @@ __global__ __launch_bounds__(256) void k_us_init_wf(const UsArgs a, float4 *st, 
     if (i >= a.n_paths) return;
     const uint32_t ray_id = udiv_fast(i, a.div_ppr);
     const uint32_t ang = udiv_fast(ray_id, a.div_ne), el = ray_id - ang * a.p.n_elements;
-    const V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));
-    const V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);
+    V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));
+    V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);
+    float amp = 1.0f, tof = 0.0f;
+    if (a.p.primary == PBRT_US_PRIMARY_EMITTER)  // the path's own ray from CustomEmitter.sample_ray (kernels_us.h us_emitter_primary)
+        us_emitter_primary(a.p, a.p.sensor_to_world, ray_id, a.path_first + (i - ray_id * a.ppr_pass), ang, el, a.seed, &o, &d, &amp, &tof);
     const size_t cp = a.cap;
-    const float4 q0 = {o.x, o.y, o.z, 1.0f}, q1 = {d.x, d.y, d.z, 1.0f}, q2 = {0.0f, 0.0f, __uint_as_float(i), __uint_as_float(0xffffffffu)},
+    const float4 q0 = {o.x, o.y, o.z, amp}, q1 = {d.x, d.y, d.z, 1.0f}, q2 = {tof, 0.0f, __uint_as_float(i), __uint_as_float(0xffffffffu)},
                  q3 = {0.0f, 0.0f, 0.0f, 0.0f};
     st[i] = q0;
     st[cp + i] = q1;

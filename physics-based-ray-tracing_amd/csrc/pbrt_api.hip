@@ -1642,6 +1642,18 @@ int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx) {
 template <bool FIRST>
 static int launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     hipStream_t st = s->ctx->stream;
+    if (FIRST && a.p.primary == PBRT_US_PRIMARY_EMITTER) {  // every path draws its primary ray from CustomEmitter.sample_ray
+        switch (s->accel_kernel) {
+            case ACCEL_K_BRUTE:
+                hipLaunchKernelGGL((k_us_bounce<true, ACCEL_K_BRUTE, true>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+                return PBRT_OK;
+            case ACCEL_K_BRUTE_BIG:
+                hipLaunchKernelGGL((k_us_bounce<true, ACCEL_K_BRUTE_BIG, true>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+                return PBRT_OK;
+            default:
+                return s->ctx->fail(PBRT_E_UNSUPPORTED, "launch_us: emitter primary rays on BVH scenes run as streams (us_wf_pass)");
+        }
+    }
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
             hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
@@ -1755,7 +1767,15 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
     NEED(c, (uint64_t)p->n_angles * p->n_elements * p->time_samples < 0xffffffffull);  // channel index is 32-bit (echo bins)
     NEED(c, p->max_depth > 0 && ppr > 0 && p->sound_speed > 0 && p->fs > 0);
-    NEED(c, p->max_depth < 0x40000000u);  // RNG block = bounce index; bit 30 marks a path's second block of a bounce
+    NEED(c, p->max_depth < 0x40000000u);  // RNG block = bounce index; bit 30 marks a path's second block of a bounce, bit 31 the emitter's
+    NEED(c, p->primary <= PBRT_US_PRIMARY_EMITTER);
+    const bool emit = p->primary == PBRT_US_PRIMARY_EMITTER;
+    if (emit) {  // CustomEmitter as the source of the primary rays: its elements are the acquisition's (include/pbrt_hip.h)
+        const pbrt_us_emitter &E = p->emitter;
+        NEED(c, E.number_of_elements == p->n_elements && E.number_of_rays_per_element > 0 && E.speed_of_sound > 0.0f);
+        NEED(c, std::isfinite(E.pitch) && std::isfinite(E.element_width) && std::isfinite(E.element_height) && std::isfinite(E.radius));
+        NEED(c, std::isfinite(E.steering_angle_min) && std::isfinite(E.steering_angle_max) && std::isfinite(E.opening_angle));
+    }
     HIPCHK(c, hipSetDevice(c->device));
     int rc = set_lds_attr(s);
     if (rc) return rc;
@@ -1851,7 +1871,10 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
-    HIPCHK(c, hipMemcpyAsync(d_tx, tx.data(), (size_t)n_rays * 4, hipMemcpyHostToDevice, st));
+    if (emit)  // the ray's own emission time rides in its time of flight (CustomEmmitter.py:93-94); t0 of :329 is 0
+        HIPCHK(c, hipMemsetAsync(d_tx, 0, (size_t)n_rays * 4, st));
+    else
+        HIPCHK(c, hipMemcpyAsync(d_tx, tx.data(), (size_t)n_rays * 4, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_dir, dir0.data(), (size_t)NA * 12, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(d_ex, ex.data(), (size_t)NE * 4, hipMemcpyHostToDevice, st));
     const size_t nchan = (size_t)n_rays * T;
@@ -1887,7 +1910,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     a.div_ne = make_fastdiv(NE);
     for (uint32_t n : {0u, 1u, NE - 1, NE, NE + 1, n_rays - 1, n_rays}) NEED(c, udiv_fast_host(n, a.div_ne) == n / NE);
     // first-bounce tables (kernels_us.h k_us_first): worth it once a ray has more paths than receive elements
-    if (ppr >= NE && !(p->quirks & PBRT_USQ_NO_FIRST_TABLES)) {
+    if (ppr >= NE && !(p->quirks & PBRT_USQ_NO_FIRST_TABLES) && !emit) {  // (emitter rays: every path has its own origin)
         float4 *fh = (float4 *)c->buf("us_first_hit", (size_t)n_rays * 16);
         float4 *fv = (float4 *)c->buf("us_first_rx", (size_t)n_rays * NE * 16);
         if (!fh || !fv) return PBRT_E_NOMEM;
@@ -2263,17 +2286,30 @@ static int das_check(pbrt_ctx *ctx, const pbrt_das_params *p) {
     NEED(ctx, p->n_angles > 0 && p->n_elements > 0 && p->time_samples > 1 && p->fs > 0.0f && p->sound_speed > 0.0f);
     NEED(ctx, p->interpolation <= PBRT_DAS_LINEAR && p->f_number >= 0.0f);
     NEED(ctx, p->nx > 0 && p->nz > 0 && (uint64_t)p->nx * p->nz < 0xffffffffull);
-    NEED(ctx, div_up(p->nx, DAS_TILE) <= 65535u);
+    NEED(ctx, (uint64_t)div_up(p->nx, DAS_TILE) * (div_up(p->nz, DAS_TILE) + DAS_BANDS) * DAS_XCDS < 0x7fffffffull);
     return PBRT_OK;
 }
 static int das_enqueue(pbrt_ctx *c, const pbrt_das_params *p, const float *dd, const float *dt, const float *de, const float *dx,
                        const float *dz, float *dout) {
     ImgTimer tm(c, IMG_DAS);
-    const dim3 grid(div_up(p->nz, DAS_TILE), div_up(p->nx, DAS_TILE)), block(256);
+    DasGrid g;
+    g.ntx = div_up(p->nx, DAS_TILE);
+    g.ntz = div_up(p->nz, DAS_TILE);
+#ifdef DAS_NO_XCD_BANDS
+    g.m = g.ntz;
+    const uint32_t blocks = g.ntx * g.ntz;
+#else
+    // z-tiles of the largest XCD share (bands k and 15 - k, kernels_beamform.h das_tile_of); the grid gives every XCD that many slots
+    g.m = 0;
+    auto lo = [&](uint32_t band) { return (band * g.ntz + DAS_BANDS - 1u) / DAS_BANDS; };
+    for (uint32_t k = 0; k < DAS_XCDS; ++k) g.m = std::max(g.m, (lo(k + 1) - lo(k)) + (lo(DAS_BANDS - k) - lo(DAS_BANDS - 1u - k)));
+    const uint32_t blocks = DAS_XCDS * g.ntx * std::max(g.m, 1u);
+#endif
+    const dim3 grid(blocks), block(64 * DAS_SPLIT);
     if (p->interpolation == PBRT_DAS_NEAREST)
-        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_NEAREST>, grid, block, 0, c->stream, *p, dd, dt, de, dx, dz, dout);
+        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_NEAREST>, grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, dout);
     else
-        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_LINEAR>, grid, block, 0, c->stream, *p, dd, dt, de, dx, dz, dout);
+        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_LINEAR>, grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, dout);
     c->img_das_bytes = ((uint64_t)p->n_angles * p->n_elements * p->time_samples + (uint64_t)p->nx * p->nz) * 4;
     HIPCHK(c, hipGetLastError());
     return PBRT_OK;

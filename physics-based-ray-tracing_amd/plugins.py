@@ -297,6 +297,7 @@ class CustomEmitter(Emitter):
     correctly spelled method is called.)  Not part of the radiance light list: the integrator
     never calls it."""
     _param_attr = {"rays_per_element": "number_of_rays_per_element"}
+    is_transducer = True  # a source of acoustic rays, not a light of the radiance scene (scene.flatten skips it)
 
     def __init__(self, props):
         super().__init__(props)
@@ -716,6 +717,13 @@ class UltraIntegrator(SamplingIntegrator):
         if self.pulse_model == "gaussian":
             self.quirks |= _capi.USQ_NO_CARRIER
         self.max_path_len = 0.2  # CustomIntegrator.py:307,372
+        # Where a path's primary ray comes from: "element" = the integrator's own deterministic ray (CustomIntegrator.py:264-273);
+        # "emitter" = every path draws its ray from the scene's CustomEmitter.sample_ray (CustomEmmitter.py:81-107), the
+        # (angle, element) grid stratifying the emitter's element pick and steering range  [DEFINE, DESIGN D15: the reference
+        # never connects the two classes; BASELINE config 3 names them together]
+        self.primary_rays = str(props.get("primary_rays", "element"))
+        if self.primary_rays not in ("element", "emitter"):
+            raise ValueError("primary_rays must be 'element' or 'emitter'")
 
     # channel_buf (CustomIntegrator.py:43,260; read at USMain.py:103): a host array, as in the reference.  When an acquisition
     # left its result in HBM (us_render keeps the whole loop on the device) the copy to the host happens on first read.
@@ -760,6 +768,16 @@ class UltraIntegrator(SamplingIntegrator):
         p.sensor_to_world = _capi.mat12(T)
         p.max_path_len = self.max_path_len
         p.quirks = int(self.quirks if quirks is None else quirks)
+        p.primary = _capi.US_PRIMARY_ELEMENT
+        if self.primary_rays == "emitter":
+            ems = [e for e in (scene.emitters() if scene is not None else []) if getattr(e, "is_transducer", False)]
+            if not ems:
+                raise ValueError("primary_rays='emitter' needs an 'ultrasound_emitter' (CustomEmitter) in the scene")
+            if ems[0].number_of_elements != self.n_elements:
+                raise ValueError(f"the emitter has {ems[0].number_of_elements} elements, the integrator {self.n_elements}: "
+                                 "the acquisition grid stratifies the emitter's elements, they must be the same array")
+            p.primary = _capi.US_PRIMARY_EMITTER
+            p.emitter = ems[0]._desc()
         return p
 
     def _acquire(self, scene, quirks, paths_per_ray=None, path_offset=0, norm_paths=None, seed=None, out_dev=None, pulse=None):

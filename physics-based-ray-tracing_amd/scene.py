@@ -500,6 +500,8 @@ class Scene(Object):
             light_prims += list(range(offsets[si], offsets[si] + len(rec)))
             light_cdf += cdf.astype(np.float32).tolist()
         for em in self._emitters:
+            if getattr(em, "is_transducer", False):  # CustomEmitter: a source of acoustic rays (UltraIntegrator primary_rays="emitter"), no light
+                continue
             e = np.zeros(1, dtype=_capi.EMITTER_DTYPE)
             kind, rad, pos = em.device_emitter()
             e["type"] = kind

@@ -75,6 +75,22 @@ US_SCENES = {
                 dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
                 dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
         seed=7, ppr=3),
+    # BASELINE config 3 read literally ("Sphere_Box.xml with CustomBSDF + CustomEmmitter"): the same phantom, every path's primary ray
+    # drawn from CustomEmitter.sample_ray (CustomEmmitter.py:81-107) -- jitter inside the element, a steering angle from the a-th
+    # fifth of [-15, 15] degrees, the element's steering delay, the cosine weight (PBRT_US_PRIMARY_EMITTER, include/pbrt_hip.h)
+    "sphere_box_emitter": dict(
+        params=dict(max_depth=10, fs=50e6, frequency=3e6, sound_speed=1480.0, attenuation=0.1, main_beam_angle=24.0, cutoff_angle=30.0,
+                    n_elements=64, pitch=1.2e-4, time_samples=10000, angles_deg=[-15.0, -7.5, 0.0, 7.5, 15.0]),
+        emitter=dict(number_of_elements=64, pitch=1.2e-4, element_width=1.0e-4, element_height=5.0e-4, radius=0.0, opening_angle=0.0,
+                     number_of_rays_per_element=3, speed_of_sound=1480.0, steering_angle_min=-15.0, steering_angle_max=15.0),
+        look_at=([0, 0, 0], [0, 0, 0.05], [0, 1, 0]),
+        shapes=[dict(type="sphere", center=[0, 0, 0.08], radius=0.06, impedance=7.8, roughness=0.9),
+                dict(type="rectangle", to_world=Tr(0, 0, 0.37) @ Ry(180) @ Sc(0.15, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(-0.15, 0, 0.12) @ Ry(90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0.15, 0, 0.12) @ Ry(-90) @ Sc(0.25, 0.15, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, 0.15, 0.12) @ Rx(90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7),
+                dict(type="rectangle", to_world=Tr(0, -0.15, 0.12) @ Rx(-90) @ Sc(0.15, 0.25, 1), impedance=7.8, roughness=0.7)],
+        seed=17, ppr=3),
     # second-bounce ECHOES: in the two scenes above a path that goes on never deposits again (plate: it leaves the cut-off cone
     # or dies; sphere_box: it continues inside the sphere, from where no receive element is visible).  Here a narrow plate 2 cm
     # ahead, 7.5 mm off axis and tilted by 12 degrees, in front of a wall at 5 cm: under the reference's arithmetic the
@@ -154,6 +170,20 @@ def build_shapes(desc):
     return out
 
 
+EMIT_BLOCK = 0x80000000   # the RNG block of a path's emitter draws (include/pbrt_hip.h PBRT_US_PRIMARY_EMITTER)
+
+
+def emitter_primary(S, a, e, ray, k):
+    """the primary ray of path k of the (angle a, element e) pair when the scene names an emitter: CustomEmitter.sample_ray(0,
+    (e + 1/2) / N, (u.x, u.y), (a + u.z) / n_angles) -- the acquisition grid stratifies the element pick and the steering range"""
+    if "emitter" not in S:
+        return None
+    P = S["params"]
+    u = rt.rng4(ray, k, EMIT_BLOCK, S["seed"])
+    o, d, t, w, _ = rt.emitter_sample_ray(S["emitter"], 0.0, (e + 0.5) / P["n_elements"], (u[0], u[1]), (a + u[2]) / len(P["angles_deg"]))
+    return o, d, t, w
+
+
 def make_k9(name, S, variant="scalar"):
     shapes = build_shapes(S["shapes"])
     P, seed, ppr = S["params"], S["seed"], S["ppr"]
@@ -165,7 +195,8 @@ def make_k9(name, S, variant="scalar"):
         for e in range(NE):
             ray = a * NE + e
             for k in range(ppr):
-                out = rt.us_trace_single_ray(shapes, T, P, a, e, lambda dep: rt.rng4(ray, k, dep, seed), variant)
+                out = rt.us_trace_single_ray(shapes, T, P, a, e, lambda dep: rt.rng4(ray, k, dep, seed), variant,
+                                             primary=emitter_primary(S, a, e, ray, k))
                 n_bounces += len(out)
                 for r in out:
                     recs.append(r)
@@ -186,12 +217,17 @@ def make_k9(name, S, variant="scalar"):
     keys = sorted(bins)
     # single-bounce BSDF records: well-conditioned ones, spread over lobes / TIR / depths
     good = [r for r in recs if r["margin"] >= 1e-2]
+    if "emitter" in S:
+        # emitter rays meet the sphere at every incidence: micro-normals within 1.5 degrees of grazing (pdf = 1 / (4 |wi . m|) > 10)
+        # pass the decision margin but leave f32 four digits of the pdf; the records are for well-conditioned samples
+        good = [r for r in good if r["pdf"] <= 10.0]
     pick = []
     for cond in (lambda r: r["tir"], lambda r: r["reflect"] and not r["tir"], lambda r: not r["reflect"], lambda r: r["depth"] >= 1):
         sel = [r for r in good if cond(r)]
         pick += sel[:: max(1, len(sel) // 16)][:16]
     tag = name if variant == "scalar" else f"{name}_{variant}"
     meta = dict(scene=name, variant=variant, params=P, look_at=S["look_at"], seed=seed, paths_per_ray=ppr, n_bounces=n_bounces,
+                **({"emitter": S["emitter"]} if "emitter" in S else {}),
                 shapes=[{k: (np.asarray(v).tolist() if k in ("to_world", "center") else v) for k, v in d.items()} for d in S["shapes"]],
                 depth_histogram={str(d): sum(1 for r in recs if r["depth"] == d) for d in sorted({r["depth"] for r in recs})},
                 deposited_by_depth={str(d): sum(1 for r in recs if r["depth"] == d and r["deposited"]) for d in sorted({r["depth"] for r in recs})})

@@ -324,8 +324,12 @@ def us_setup(P):
     return elem_x.astype(np.float64), angles_rad, tx_delay.astype(np.float32).astype(np.float64)    # :257
 
 
-def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant="scalar"):
+def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant="scalar", primary=None):
     """draws(depth) -> (u_recv, s1, s2, u_rr): the four uniforms of one bounce (:319, :337, :365).
+    primary: None = the integrator's own ray (:264-273); else (o, d, ray time, weight) of CustomEmitter.sample_ray in the
+    transducer's frame (emitter_sample_ray below): the path starts there -- origin and direction taken to the world like :273,
+    the ray's time as its initial time of flight (t0 = 0), its weight as its initial amplitude (the library's
+    PBRT_US_PRIMARY_EMITTER; the reference itself never connects its emitter to its integrator).
     variant "scalar": _trace_single_ray of simulate_acquisition_parallel (:262-376, what USMain.py calls);
     variant "drjit": the body of simulate_acquisition's dr.while_loop (:137-226), where it differs -- the draws are taken
     while the loop body is TRACED (llvm_ad_mono, USMain.py:12), i.e. once per ray: every bounce sees draws(0) (:153,173-174,
@@ -344,6 +348,10 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
     direction = vec(math.sin(a_rad), 0.0, math.cos(a_rad))                                          # :271
     ray_o, ray_d = R @ origin + tr, normalize(R @ direction)                                        # :273
     amp, atten, tof, geo_len, depth, active = 1.0, 1.0, 0.0, 0.0, 0, True                           # :276-281
+    if primary is not None:
+        e_o, e_d, e_time, e_weight = primary                                                        # CustomEmmitter.py:100-107
+        ray_o, ray_d = R @ np.asarray(e_o, dtype=np.float64) + tr, normalize(R @ np.asarray(e_d, dtype=np.float64))
+        amp, tof, t0 = float(e_weight), float(e_time), 0.0
     trans_normal_world = normalize(R @ vec(0.0, 0.0, 1.0))                                          # :292, :369
     alpha_m, alpha_c = math.radians(P["main_beam_angle"]), math.radians(P["cutoff_angle"])          # :345
     out = []

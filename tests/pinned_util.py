@@ -70,6 +70,9 @@ def k9_scene(mi, meta):
                         "time_samples": P["time_samples"], "angles": np.asarray(P["angles_deg"], np.float32),
                         "paths_per_ray": meta["paths_per_ray"], "seed": meta["seed"]},
          "sensor": {"type": "ultrasound_sensor", "to_world": T().look_at(*meta["look_at"])}}
+    if "emitter" in meta:   # every path draws its primary ray from the scene's CustomEmitter (PBRT_US_PRIMARY_EMITTER)
+        d["integrator"]["primary_rays"] = "emitter"
+        d["emitter"] = dict(meta["emitter"], type="ultrasound_emitter")
     for i, s in enumerate(meta["shapes"]):
         bs = {"type": "ultrasound_bsdf", "impedance": s["impedance"], "roughness": s["roughness"]}
         if s["type"] == "sphere":

@@ -96,3 +96,17 @@ def test_invalid_arguments_return_error_codes(capi):
     assert lib.pbrt_ray_intersect(None, 0, None, None, None, None, None, None, None) == -1
     assert lib.pbrt_ctx_set_workspace_limit(None, 0) == -1 and lib.pbrt_ctx_trim(None, None) == -1
     assert lib.pbrt_ctx_destroy(None) == 0 and lib.pbrt_scene_destroy(None) == 0
+
+
+def test_the_analytic_gpu_tests_do_not_use_the_oracle():
+    """tests/test_gpu_analytic.py (K8 on the device) must stand without the CPU restatement: no import of oracle/, no `ob` fixture"""
+    import ast
+    src = open(os.path.join(ROOT, "tests", "test_gpu_analytic.py")).read()
+    tree = ast.parse(src)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Import):
+            assert not any(a.name.split(".")[0] == "oracle" for a in node.names)
+        elif isinstance(node, ast.ImportFrom):
+            assert (node.module or "").split(".")[0] not in ("oracle", "conftest")
+        elif isinstance(node, ast.FunctionDef) and node.name.startswith("test_"):
+            assert "ob" not in [a.arg for a in node.args.args], node.name

@@ -10,7 +10,7 @@ from pinned_util import check_k10, check_k11, check_k9_bins, check_k9_records, k
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring", "sphere_box_emitter"])
 def test_k9_hip_single_bounce_records(mi, capi, name):
     """UltraBSDF.sample (CustomBSDF.py:87-175) through the plugin API -> pbrt_bsdf_sample"""
     z, meta = load_k9(name)
@@ -23,7 +23,7 @@ def test_k9_hip_single_bounce_records(mi, capi, name):
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring", "sphere_box_emitter"])
 @pytest.mark.parametrize("tables", [True, False])
 def test_k9_hip_echo_values(mi, capi, name, tables):
     """the whole acquisition (CustomIntegrator.py:235-376): arrival bins, pressures and bare envelopes of every echo,

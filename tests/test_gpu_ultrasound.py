@@ -36,7 +36,11 @@ def check(buf, ref):
                                                ("us_cone_floating.xml", 60, 8, dict(tessellate="true")),
                                                # the ring of BASELINE config 4 as phantom (1157 primitives: k_trace + k_us_shade): with the
                                                # first-bounce tables, and with fewer paths per ray than elements (primary rays traced)
-                                               ("us_testring.xml", 100, 9, {}), ("us_testring.xml", 24, 10, {})])
+                                               ("us_testring.xml", 100, 9, {}), ("us_testring.xml", 24, 10, {}),
+                                               # BASELINE config 3 "with CustomBSDF + CustomEmmitter": every path's primary ray from
+                                               # CustomEmitter.sample_ray (k_us_bounce<true, ., EMIT>; no first-bounce tables)
+                                               ("us_sphere_box.xml", 300, 11, dict(primary_rays="emitter")),
+                                               ("us_sphere_box.xml", 16, 12, dict(primary_rays="emitter"))])
 def test_acquisition_matches_oracle(mi, ob, scene, ppr, seed, kw):
     sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=seed, **kw)
     ui = sc.integrator()
@@ -319,3 +323,40 @@ def test_mesh_phantom_variants_of_the_acquisition_loop(mi, ob, capi, case):
     assert (buf != 0).sum() > 500
     if case == "depth1":
         assert st["live"][1] == 0 and st["bounce_launches"] == 2 + 2     # trace + shade of bounce 0 (the rays come from k_us_init_wf), then the flush
+
+
+def test_emitter_primary_rays_on_a_mesh_phantom_and_their_refusals(mi, ob, capi):
+    """PBRT_US_PRIMARY_EMITTER on a BVH scene (k_us_init_wf writes the emitter's rays, then k_trace + k_us_shade), the quirk
+    switches with it, what it changes against the integrator's own rays, and the error codes: an emitter whose array is not the
+    integrator's, a scene without one."""
+    T = mi.ScalarTransform4f
+    sc = mi.load_file(scene_path("us_testring.xml"), paths_per_ray=48, seed=6)
+    ui = sc.integrator()
+    own = ui._acquire(sc, ui.quirks)
+    em = mi.CustomEmitter(mi.Properties("ultrasound_emitter", dict(number_of_elements=ui.n_elements, pitch=ui.pitch, element_width=1e-4,
+                                                                   element_height=4e-4, number_of_rays_per_element=48, speed_of_sound=ui.sound_speed,
+                                                                   steering_angle_min=-12.0, steering_angle_max=12.0)))
+    sc._emitters.append(em)
+    ui.primary_rays = "emitter"
+    p = ui.us_params(sc)
+    assert p.primary == capi.US_PRIMARY_EMITTER and p.emitter.number_of_elements == ui.n_elements
+    got = ui._acquire(sc, ui.quirks)
+    ref, tx = ob.OracleScene.from_scene(sc).us_acquire(p, 6, 48)
+    check(got, ref)
+    assert np.array_equal(ui.transmission_delays_buf, tx)                  # the table of the nominal angles, as before
+    assert np.abs(got).max() > 0 and not np.array_equal(got != 0, own != 0)   # other rays, other echoes
+    # the emitter's weight max(0, d.n) / N_total_rays is the path's amplitude: the echoes are ~ 1 / (64 * 48) of the integrator's own
+    assert np.abs(got).max() < 0.01 * np.abs(own).max()
+    q = ui.quirks | capi.USQ_DRJIT_VARIANT
+    check(ui._acquire(sc, q), ob.OracleScene.from_scene(sc).us_acquire(ui.us_params(sc, q), 6, 48)[0])
+    em.number_of_elements = ui.n_elements // 2
+    with pytest.raises(ValueError, match="elements"):
+        ui.us_params(sc)
+    p.emitter.number_of_elements = 7                                          # past the Python check: the library refuses it
+    dev = sc.device()
+    buf = np.empty((ui.n_angles, ui.n_elements, ui.time_samples), np.float32)
+    rc = dev.ctx.lib.pbrt_us_acquire(dev.handle, p, 6, 4, 0, 4, buf.ctypes.data, None)
+    assert rc == -1 and b"number_of_elements" in dev.ctx.lib.pbrt_last_error(dev.ctx.handle)
+    sc._emitters.clear()
+    with pytest.raises(ValueError, match="ultrasound_emitter"):
+        ui.us_params(sc)

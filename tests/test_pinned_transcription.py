@@ -15,7 +15,7 @@ from pinned_util import SAFE, check_k10, check_k11, check_k9_bins, check_k9_reco
 sys.path.insert(0, GOLDEN)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring", "sphere_box_emitter"])
 def test_k9_fixture_is_what_the_transcription_produces(name):
     """the committed fixture equals a fresh run of the transcription (first rays of every angle)"""
     import make_pinned as mp
@@ -31,7 +31,8 @@ def test_k9_fixture_is_what_the_transcription_produces(name):
         for e in range(NE):
             ray = a * NE + e
             for k in range(S["ppr"]):
-                for r in rt.us_trace_single_ray(shapes, T, S["params"], a, e, lambda dep: rt.rng4(ray, k, dep, S["seed"])):
+                for r in rt.us_trace_single_ray(shapes, T, S["params"], a, e, lambda dep: rt.rng4(ray, k, dep, S["seed"]),
+                                                primary=mp.emitter_primary(S, a, e, ray, k)):
                     if r["deposited"]:
                         key = (a, r["recv"], r["t_idx"])
                         acc[key] = acc.get(key, 0.0) + r["pressure"]
@@ -50,7 +51,7 @@ def test_rng_of_the_transcription_is_the_librarys(ob, capi):
     assert np.all((u >= 0) & (u < 1)) and len(np.unique(u)) == u.size
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring", "sphere_box_emitter"])
 def test_k9_oracle_single_bounce_records(ob, capi, name):
     z, meta = load_k9(name)
 
@@ -61,7 +62,7 @@ def test_k9_oracle_single_bounce_records(ob, capi, name):
     check_k9_records(z, meta, sample)
 
 
-@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring"])
+@pytest.mark.parametrize("name", ["plate", "sphere_box", "two_plates", "plate_box", "testring", "sphere_box_emitter"])
 def test_k9_oracle_echo_values(mi, ob, capi, name):
     """every echo of every path: arrival bin, pressure (CustomIntegrator.py:340-354) and, with the carrier off, the
     envelope atten * amp * w_i * w_o alone; in two_plates the second-bounce echoes reach the receive elements (162 of

@@ -1,20 +1,29 @@
-"""wall time of the image-formation steps at the reference's sizes (5 x 64 x 10000 channel buffer, lambda / 4 grid of
-USMain.py:180-194: 651 x 399 pixels) through the host API (includes the 12.8 MB upload and the image download)"""
-import os, sys, time
+"""Device time of the image-formation kernels at the sizes of the reference's us_render (USMain.py:26-90, :180-194: 5 x 64 x 10000
+channel buffer, lambda / 4 grid at 5 MHz / 1540 m/s = 1040 x 638 pixels), data resident in HBM, HIP events on the library's
+stream (pbrt_ctx_set_profiling).  PBRT_HIP_LIB selects the build; the md5 of each result says whether two builds agree."""
+import hashlib, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import pbrt_amd as mi
 rng = np.random.default_rng(0)
-A, E, T, c, fs, pitch = 5, 64, 10000, 1480.0, 50e6, 1.2e-4
+A, E, T, c, fs, pitch, fc = 5, 64, 10000, 1540.0, 50e6, 1.2e-4, 5e6
 data = rng.normal(size=(A, E, T)).astype(np.float32)
 ex = (pitch * (np.arange(E, dtype=np.float32) - (E - 1) / 2)).astype(np.float32)
 tx = (ex[None, :].astype(np.float64) * np.sin(np.deg2rad([-15, -7.5, 0, 7.5, 15]))[:, None] / c).astype(np.float32)
-lam = c / 3e6
+lam = c / fc
 x = np.arange(-0.04, 0.04 + lam / 4, lam / 4); z = np.arange(0.001, 0.05 + lam / 4, lam / 4)
-for name, fn in (("das_beamform", lambda: mi.das_beamform(data, tx, ex, x, z, fs, c)),):
-    img = fn()
-    t = time.perf_counter(); [fn() for _ in range(5)]; dt = (time.perf_counter() - t) / 5
-    print(f"{name}: {dt*1e3:.2f} ms per call, {len(x)} x {len(z)} pixels, {len(x)*len(z)*A*E/dt/1e9:.2f} G (pixel,angle,element) sums/s", flush=True)
-env = mi.envelope(img)
-t = time.perf_counter(); [mi.envelope(img) for _ in range(5)]; print(f"envelope: {(time.perf_counter()-t)/5*1e3:.2f} ms per call", flush=True)
-t = time.perf_counter(); [mi.log_compress(env) for _ in range(5)]; print(f"log_compress: {(time.perf_counter()-t)/5*1e3:.2f} ms per call", flush=True)
+cx = mi.default_context()
+d = {k: mi.DeviceBuffer.from_host(cx, v.astype(np.float32)) for k, v in dict(data=data, tx=tx, ex=ex, x=x, z=z).items()}
+bf = mi.das_beamform(d["data"], d["tx"], d["ex"], d["x"], d["z"], fs, c)
+env = mi.envelope(bf); img = mi.log_compress(env)
+cx.set_profiling(True)
+acc = dict(das_ms=0.0, envelope_ms=0.0, log_ms=0.0)
+N = 10
+for _ in range(N):
+    mi.das_beamform(d["data"], d["tx"], d["ex"], d["x"], d["z"], fs, c, out=bf)
+    mi.envelope(bf, out=env); mi.log_compress(env, out=img)
+    st = cx.image_stats()
+    for k in acc: acc[k] += st[k] / N
+h = lambda b: hashlib.md5(b.numpy().tobytes()).hexdigest()[:10]
+print(f"{os.environ.get('PBRT_HIP_LIB', 'default'):40s} {len(x)} x {len(z)}  das {acc['das_ms']*1e3:7.1f} us  envelope {acc['envelope_ms']*1e3:6.1f} us  "
+      f"log {acc['log_ms']*1e3:5.1f} us   md5 das {h(bf)} env {h(env)} img {h(img)}", flush=True)

@@ -83,7 +83,7 @@ CONFIGS = {
     # BASELINE config 3 read literally ("Sphere_Box.xml with CustomBSDF + CustomEmmitter"): every path draws its primary ray from
     # CustomEmitter.sample_ray (PBRT_US_PRIMARY_EMITTER, DESIGN D15) -- no first-bounce tables, bounce 0 traced by all 268 M paths
     "us_sphere_box_emitter": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,
-                                  load=dict(primary_rays="emitter", paths_per_ray=838912),
+                                  load=dict(primary_rays="emitter"),
                                   metric="Msamples/s on MitsubaScenes/Sphere_Box.xml phantom with CustomEmitter primary rays, 5 x 64 rays x 838912 paths (ultrasound, UltraBSDF, max_depth 10)",
                                   what="sphere + 5 walls, UltraBSDF, primary rays from CustomEmitter.sample_ray (64 elements, +-15 degrees in 5 strata), channel buffer 5 x 64 x 10000"),
     "us_sphere_box": dict(kind="ultrasound", scene="us_sphere_box.xml", ppr=838912, baseline_config=3,

@@ -213,8 +213,11 @@ typedef struct pbrt_us_emitter {
  *          angle drawn uniformly from the a-th of n_angles equal parts of [steering_angle_min, steering_angle_max] (:85-87); the
  *          ray is taken to the world with the sensor transform like the integrator's own (:272-273), its `time` (the element's
  *          steering delay -x sin(psi) / c, :93-94) is the path's initial time of flight (t0 of :329 is then 0) and its weight
- *          max(0, d.n) / N_total_rays (:97-98) the path's initial amplitude (:276 has 1).  emitter.number_of_elements must equal
- *          n_elements.  No first-bounce tables: every path walks the scene from its own origin. */
+ *          max(0, d.n) / N_total_rays (:97-98) multiplies every echo the path deposits -- as Mitsuba's render loop multiplies what
+ *          Integrator.sample returns by the weight of the sampled ray; the path's own amplitude starts at 1 (:276), so the
+ *          Russian roulette of :364-367, which reads that amplitude as a survival probability, is the integrator's.
+ *          emitter.number_of_elements must equal n_elements.  No first-bounce tables: every path walks the scene from its own
+ *          origin. */
 #define PBRT_US_PRIMARY_ELEMENT 0u
 #define PBRT_US_PRIMARY_EMITTER 1u
 

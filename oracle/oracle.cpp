@@ -1123,6 +1123,16 @@ struct EmitRay {
     V3 o, d;
     float time, weight, pdf_pos;
 };
+// sin / cos of a steering or element angle: the fixed polynomial shared with the device up to 45 degrees (omath.h sincos_pi4), the
+// library routines beyond -- so that the first bounce of an emitter ray sees the same bits on both sides (kernels_us.h emit_sincos)
+static inline void emit_sincos(float x, float *s, float *c) {
+    if (fabsf(x) <= kPiOver4) {
+        sincos_pi4(x, s, c);
+    } else {
+        *s = sinf(x);
+        *c = cosf(x);
+    }
+}
 static inline EmitRay emitter_ray(const pbrt_us_emitter &e, float time, float s1, float s2x, float s2y, float s3) {
     const float N = (float)e.number_of_elements;
     const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
@@ -1137,8 +1147,10 @@ static inline EmitRay emitter_ray(const pbrt_us_emitter &e, float time, float s1
         float span = e.opening_angle * (kPi / 180.0f);
         float lo = -span / 2.0f, hi = span / 2.0f;
         float th = N > 1.0f ? fmaf(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
-        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
+        float sth, cth;
+        emit_sincos(th, &sth, &cth);
+        c = {e.radius * sth, 0.0f, e.radius * cth};
+        nrm = normalize(v3(sth, 0.0f, cth));                                                // :49
     }
     float dx = (s2x - 0.5f) * e.element_width, dy = (s2y - 0.5f) * e.element_height;        // :64-65
     EmitRay r;
@@ -1146,8 +1158,10 @@ static inline EmitRay emitter_ray(const pbrt_us_emitter &e, float time, float s1
     r.pdf_pos = 1.0f / (N * e.element_width * e.element_height);                            // :77
     float pmin = e.steering_angle_min * (kPi / 180.0f), pmax = e.steering_angle_max * (kPi / 180.0f);
     float psi = fmaf(s3, pmax - pmin, pmin);                                                // :85-87
-    r.d = {sinf(psi), 0.0f, cosf(psi)};                                                     // :90
-    float delay = -(r.o.x * sinf(psi)) / e.speed_of_sound;                                  // :93
+    float spsi, cpsi;
+    emit_sincos(psi, &spsi, &cpsi);
+    r.d = {spsi, 0.0f, cpsi};                                                               // :90
+    float delay = -(r.o.x * spsi) / e.speed_of_sound;                                       // :93
     r.time = time + delay;                                                                  // :94
     float fd = fmaxf(0.0f, dot(r.d, nrm));                                                  // :97
     r.weight = fd / total_rays;                                                             // :98
@@ -1193,7 +1207,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                 const uint32_t k = path_offset + kk;
                 V3 o = o0, d = d0;
                 float amp = 1.0f, atten = 1.0f, tof = 0.0f, geo_len = 0.0f;                    // :276-279
-                float t0 = t0_elem;
+                float t0 = t0_elem, w_ray = 1.0f;
                 if (emit) {
                     // PBRT_US_PRIMARY_EMITTER (include/pbrt_hip.h, DESIGN D15): the path's own ray from CustomEmitter.sample_ray,
                     // the (angle, element) grid stratifying the emitter's element pick and steering angle; RNG block 0x80000000
@@ -1202,7 +1216,8 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     const EmitRay r = emitter_ray(p->emitter, 0.0f, s1, ue.x, ue.y, s3);       // CustomEmmitter.py:81-107
                     o = xf_point(p->sensor_to_world, r.o);                                     // (:272-273 for the integrator's own ray)
                     d = normalize(xf_vec(p->sensor_to_world, r.d));
-                    amp = r.weight;                                                            // CustomEmmitter.py:97-98
+                    w_ray = r.weight;   // CustomEmmitter.py:97-98; multiplies every echo of the path, as Mitsuba's render loop multiplies
+                                        // what Integrator.sample returns by the ray weight (amp itself starts at 1, :276)
                     tof = r.time;                                                              // :93-94: the steering delay starts the clock
                     t0 = 0.0f;
                 }
@@ -1257,6 +1272,7 @@ int oracle_us_acquire(oracle_scene *s, const pbrt_us_params *p, uint32_t seed, u
                     float w_o = dot(d, si.ns) / num_rays;                                      // :286-287,345 (si.sh_frame.n)
                     float fd = directivity_weight_i(sec_dir, tn, am, ac) * w_o;                // :345
                     float pressure = atten * amp * fd * ((p->quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase));  // :348 / f-3
+                    pressure *= w_ray;                                                         // (x 1, or the emitter ray's weight)
                     float tf = rintf(total_time * p->fs);                                      // :351-352 (half-to-even)
                     if (p->quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
                     if (tf >= 0.0f && tf < (float)T && visible)                                // :353

@@ -57,6 +57,19 @@ struct EmitRay {
     V3 o, d;
     float time, weight, pdf_pos;
 };
+// sin / cos of a steering or element angle: up to 45 degrees (every array the reference describes) the fixed polynomial the CPU
+// restatement shares bit for bit (device_math.h sincos_pi4, ~1 ulp), beyond that the library routines.  Why it matters: the ray this
+// feeds is the input of the path's first bounce, whose pdf 1 / (4 |wi . m|) is unbounded (and MULTIPLIES the amplitude, quirk B9) --
+// an input that differs in its last bit between ocml and libm moves the few near-grazing echoes that dominate a channel buffer by
+// per cents (measured: rel. L2 2.6e-2 against the CPU restatement at 32 768 paths per ray, 2e-7 with identical inputs).
+DEV void emit_sincos(float x, float *s, float *c) {
+    if (fabsf(x) <= K_PI_OVER_4) {
+        sincos_pi4(x, s, c);
+    } else {
+        *s = sinf(x);
+        *c = cosf(x);
+    }
+}
 DEV EmitRay us_emitter_ray(const pbrt_us_emitter &e, float time, float s1, float s2x, float s2y, float s3) {
     const float N = (float)e.number_of_elements;
     const float total_rays = (float)(e.number_of_elements * e.number_of_rays_per_element);  // :17
@@ -71,8 +84,10 @@ DEV EmitRay us_emitter_ray(const pbrt_us_emitter &e, float time, float s1, float
         float span = e.opening_angle * (K_PI / 180.0f);
         float lo = -span / 2.0f, hi = span / 2.0f;
         float th = N > 1.0f ? fma_(idx, (hi - lo) / (N - 1.0f), lo) : lo;
-        c = {e.radius * sinf(th), 0.0f, e.radius * cosf(th)};
-        nrm = normalize(v3(sinf(th), 0.0f, cosf(th)));                                      // :49
+        float sth, cth;
+        emit_sincos(th, &sth, &cth);
+        c = {e.radius * sth, 0.0f, e.radius * cth};
+        nrm = normalize(v3(sth, 0.0f, cth));                                                // :49
     }
     float dx = (s2x - 0.5f) * e.element_width, dy = (s2y - 0.5f) * e.element_height;        // :64-65
     EmitRay r;
@@ -80,8 +95,10 @@ DEV EmitRay us_emitter_ray(const pbrt_us_emitter &e, float time, float s1, float
     r.pdf_pos = 1.0f / (N * e.element_width * e.element_height);                            // :77
     float pmin = e.steering_angle_min * (K_PI / 180.0f), pmax = e.steering_angle_max * (K_PI / 180.0f);
     float psi = fma_(s3, pmax - pmin, pmin);                                                // :85-87
-    r.d = {sinf(psi), 0.0f, cosf(psi)};                                                     // :90
-    float delay = -(r.o.x * sinf(psi)) / e.speed_of_sound;                                  // :93
+    float spsi, cpsi;
+    emit_sincos(psi, &spsi, &cpsi);
+    r.d = {spsi, 0.0f, cpsi};                                                               // :90
+    float delay = -(r.o.x * spsi) / e.speed_of_sound;                                       // :93
     r.time = time + delay;                                                                  // :94
     float fd = fmaxf(0.0f, dot(r.d, nrm));                                                  // :97
     r.weight = fd / total_rays;                                                             // :98
@@ -90,20 +107,23 @@ DEV EmitRay us_emitter_ray(const pbrt_us_emitter &e, float time, float s1, float
 
 // PBRT_US_PRIMARY_EMITTER (include/pbrt_hip.h, DESIGN D15): the primary ray of path k of the (angle, element) pair -- its own draw
 // from CustomEmitter.sample_ray, the acquisition grid stratifying the element pick and the steering angle, RNG block 0x80000000.
-// -> origin and direction in the world (the sensor transform, as :272-273 do for the integrator's own ray), the initial amplitude
-// (the emitter's weight) and the initial time of flight (the emitter's ray time: the element's steering delay).
+// -> origin and direction in the world (the sensor transform, as :272-273 do for the integrator's own ray), the initial time of
+// flight (the emitter's ray time: the element's steering delay) and the ray's weight, which multiplies every echo the path deposits
+// (Mitsuba's render loop multiplies what the integrator returns by the ray weight; the path's own amplitude starts at 1, :276).
 #define US_EMIT_BLOCK 0x80000000u
-DEV void us_emitter_primary(const pbrt_us_params &p, const float *M, uint32_t ray_id, uint32_t k, uint32_t ang, uint32_t el,
-                            uint32_t seed, V3 *o, V3 *d, float *amp, float *tof) {
+DEV EmitRay us_emitter_path_ray(const pbrt_us_params &p, uint32_t ray_id, uint32_t k, uint32_t ang, uint32_t el, uint32_t seed) {
     const F4 ue = rng4(ray_id, k, US_EMIT_BLOCK, seed);
     const float s1 = ((float)el + 0.5f) / (float)p.n_elements, s3 = ((float)ang + ue.z) / (float)p.n_angles;
-    const EmitRay r = us_emitter_ray(p.emitter, 0.0f, s1, ue.x, ue.y, s3);
+    return us_emitter_ray(p.emitter, 0.0f, s1, ue.x, ue.y, s3);
+}
+DEV float us_emitter_primary(const pbrt_us_params &p, const float *M, uint32_t ray_id, uint32_t k, uint32_t ang, uint32_t el,
+                             uint32_t seed, V3 *o, V3 *d, float *tof) {
+    const EmitRay r = us_emitter_path_ray(p, ray_id, k, ang, el, seed);
     *o = xf_point(M, r.o);
     *d = normalize(xf_vec(M, r.d));
-    *amp = r.weight;
     *tof = r.time;
+    return r.weight;
 }
-
 // waves per SIMD the register allocator aims for: the ultrasound bounce (GGX sampling, expf / sinf / acosf) needs
 // about 95 VGPRs: 4 waves per SIMD run it without spills.  (While same-word global atomics dominated the kernel the
 // spilling 8-wave build was the fastest -- 2.83 / 2.98 / 3.06 ms at 8 / 6 / 4 waves; with the echoes summed in LDS
@@ -112,7 +132,7 @@ DEV void us_emitter_primary(const pbrt_us_params &p, const float *M, uint32_t ra
 // 96 VGPRs (5 waves) still means two workgroups, 80 VGPRs with 4 of them spilled means three: config 3
 // 13.2 / 13.2 / 11.9 / 14.4 ms at 4 / 5 / 6 / 8 waves (8: 30 spilled).
 #define US_N_STATE 11  // origin, direction, amp, atten, tof, geo_len, home
-DEV uint32_t us_state_voff(uint32_t slot) { return (slot >> 6) * (64u * US_N_STATE * 4u) + (slot & 63u) * 4u; }
+DEV uint32_t us_state_voff(uint32_t slot, uint32_t rows = US_N_STATE) { return (slot >> 6) * (64u * rows * 4u) + (slot & 63u) * 4u; }
 #define US_AGG_LOG2 8
 #define US_AGG_BINS (1u << US_AGG_LOG2)
 #ifndef US_WAVES_PER_EU
@@ -127,10 +147,22 @@ __host__ __device__ constexpr uint32_t us_owners_per_region(int accel) {
     return rad_wave_private(accel) ? seg_threads(accel) / 64 : 1;
 }
 
-// EMIT: the instance whose first bounce draws every path's primary ray from CustomEmitter.sample_ray (PBRT_US_PRIMARY_EMITTER); an
-// instance of its own so that the deterministic-ray kernels keep their register allocation (they sit at the 6-wave budget).
-template <bool FIRST, int ACCEL, bool EMIT = false>
+// EMIT: the instances of PBRT_US_PRIMARY_EMITTER -- the first bounce draws every path's primary ray from CustomEmitter.sample_ray,
+// every echo is multiplied by the ray's weight; instances of their own so that the deterministic-ray kernels keep their register
+// allocation (they sit at the 6-wave budget).
+// Q: the behaviour switches (pbrt_us_params.quirks) as a compile-time constant, or US_Q_RUNTIME to read them from the arguments.
+// The switches are launch-uniform, and read at run time the compiler hoists every `quirks & BIT` out of the bounce loop and keeps it
+// as a 64-bit lane mask: 17 such masks were 34 of the 50 scalar registers this kernel spilled into VGPR lanes (round 4: 106
+// v_readlane / v_writelane in 1 720 VALU instructions).  The library's default set (PBRT_USQ_REFERENCE, with and without the
+// carrier) gets instances with the switches folded away; any other set runs the generic instance (same results:
+// tests/test_gpu_ultrasound.py runs both on the same job; PBRT_US_GENERIC_KERNEL=1 forces the generic one).
+// TAB: first-bounce tables present (1) / absent (0) / decided at run time (-1), for the same reason.
+#define US_Q_RUNTIME 0xffffffffu
+template <bool FIRST, int ACCEL, bool EMIT = false, uint32_t Q = US_Q_RUNTIME, int TAB = -1>
 __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_us_bounce(const UsArgs a) {
+    const uint32_t quirks = Q == US_Q_RUNTIME ? a.p.quirks : Q;
+    const bool have_hit_tab = TAB < 0 ? a.first_hit != nullptr : TAB == 1;
+    const bool have_rx_tab = TAB < 0 ? a.first_rx != nullptr : TAB == 1;
     constexpr uint32_t SEG = seg_threads(ACCEL);
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];
@@ -209,7 +241,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     // path state: tiles of 64 slots x 11 rows like the radiance kernels' (kernels_radiance.h state_voff), read and written through
     // buffer descriptors: the row offset k * 256 is an immediate of the instruction, no 64-bit address arithmetic and no
     // pointer pair per array in SGPRs (this kernel spills scalars)
-    Rsrc r_in = make_rsrc(a.in, cap * (US_N_STATE * 4u)), r_out = make_rsrc(a.out, cap * (US_N_STATE * 4u));
+    // (the EMIT instances carry a twelfth row: the weight of the path's primary ray, a factor of every echo it deposits)
+    constexpr uint32_t ROWS = EMIT ? US_N_STATE + 1u : US_N_STATE;
+    Rsrc r_in = make_rsrc(a.in, cap * (ROWS * 4u)), r_out = make_rsrc(a.out, cap * (ROWS * 4u));
     uint32_t depth = a.depth;
     uint32_t out_off, ns_acc;
     for (;;) {  // bounce loop: a single trip unless a.fuse
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     const uint32_t slot = base + it0 + lane_c;
     bool survive = false, did_seg = false;
     V3 o, d;
-    float amp, atten, tof, geo_len;
+    float amp, atten, tof, geo_len, w_ray = 1.0f;
     uint32_t home = slot;
     if (alive) {
 #ifdef PBRT_PROBE_EXTRA_VALU  // diagnostic builds only (see k_bounce)
@@ -244,10 +278,11 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             atten = 1.0f;
             tof = 0.0f;
             geo_len = 0.0f;                                                            // :276-279
-            if (EMIT) us_emitter_primary(a.p, U_M, ray_id, k, ang, el, a.seed, &o, &d, &amp, &tof);  // (a.tx is all zero then)
+            if (EMIT) w_ray = us_emitter_primary(a.p, U_M, ray_id, k, ang, el, a.seed, &o, &d, &tof);  // (a.tx is all zero then)
         } else {
-            const uint32_t v4 = us_state_voff(slot);
+            const uint32_t v4 = us_state_voff(slot, ROWS);
             constexpr uint32_t row = STATE_ROW_BYTES;
+            if (EMIT) w_ray = bld(r_in, v4 + 11 * row, 0);
             o = {bld(r_in, v4 + 0 * row, 0), bld(r_in, v4 + 1 * row, 0), bld(r_in, v4 + 2 * row, 0)};
             d = {bld(r_in, v4 + 3 * row, 0), bld(r_in, v4 + 4 * row, 0), bld(r_in, v4 + 5 * row, 0)};
             amp = bld(r_in, v4 + 6 * row, 0);
@@ -262,7 +297,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         const V3 tn = {U_TN(0), U_TN(1), U_TN(2)};
         Hit h;
         bool hit;
-        if (first && a.first_hit) {  // shared first hit of the ray (k_us_first)
+        if (first && have_hit_tab) {  // shared first hit of the ray (k_us_first)
             const float4 r = a.first_hit[ray_id];
             h.t = r.x;
             h.u = r.y;
@@ -279,13 +314,13 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             SI si = make_si<ACCEL != ACCEL_K_BRUTE>(P, o, d, h.t, h.u, h.v, a.sc.vnormals, h.slot);
             const float distance = h.t;                                                // :314
             geo_len += distance;                                                       // :315
-            const bool no_acc = (a.p.quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
+            const bool no_acc = (quirks & PBRT_USQ_NO_TOF_ACCUM) != 0;
             if (!no_acc) tof += distance * U_INVC;                                    // :316
             // B1 (Dr.Jit variant): the draws are constants of the traced loop body -- every bounce reuses block 0
-            const uint32_t block = (a.p.quirks & PBRT_USQ_FROZEN_DRAWS) ? 0u : depth;
+            const uint32_t block = (quirks & PBRT_USQ_FROZEN_DRAWS) ? 0u : depth;
             F4 u = rng4(ray_id, k, block, a.seed);
             uint32_t recv = min((uint32_t)(u.x * (float)NE), NE - 1);                  // :319
-            const bool tab = first && a.first_rx != nullptr;  // (ray, receive element) record of k_us_first
+            const bool tab = first && have_rx_tab;  // (ray, receive element) record of k_us_first
             float4 rx = {0.0f, 0.0f, 0.0f, 0.0f};
             V3 sec_dir = {0.0f, 0.0f, 0.0f};
             bool visible = false;
@@ -315,13 +350,13 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
             if (M.type == PBRT_MAT_ULTRA) {
                 // intent arithmetic (no diagonal broadcast, A2 off): the micro-normal's second variate comes from a second
                 // block of the path's stream -- u.w also decides the roulette below and must not steer the facet as well
-                const float s1b = (a.p.quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, block | 0x40000000u, a.seed).x;
-                UltraOut uo = ultra_core(M, a.p.quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
+                const float s1b = (quirks & PBRT_USQ_DIAG_SAMPLE) ? u.w : rng4(ray_id, k, block | 0x40000000u, a.seed).x;
+                UltraOut uo = ultra_core(M, quirks, wi, si.n, si.ns, u.y, u.z, s1b); // :338
                 a_resp = uo.amp;
                 bpdf = uo.pdf;
                 new_dir = to_world(fr, to_local(fr, uo.chosen));                       // CustomBSDF.py:165 + :358
             } else {
-                BSample bs = bsdf_sample(M, a.p.quirks, wi, si.n, si.ns, fr, u.y, u.z, u.w);
+                BSample bs = bsdf_sample(M, quirks, wi, si.n, si.ns, fr, u.y, u.z, u.w);
                 ok = bs.valid;
                 a_resp = bs.weight.x;
                 bpdf = bs.pdf;
@@ -338,7 +373,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                     ci = __float_as_uint(rx.z);
                 } else {
                     float tf = rintf(total_time * U_FS);                             // :351-352
-                    if (a.p.quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
+                    if (quirks & PBRT_USQ_CLAMP_TIME) tf = fminf(fmaxf(tf, 0.0f), (float)(T - 1));
                     if (tf >= 0.0f && tf < (float)T && visible) {                      // :353
                         ci = (ang * NE + recv) * T + (uint32_t)tf;                     // :354 (host checks it fits 32 bits)
                         // the echo's weight and carrier only where an echo is deposited: acosf and sinf are a tenth of the
@@ -346,11 +381,12 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                         float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);        // :286-287,345 (si.sh_frame.n)
                         fd = directivity_weight_i(sec_dir, tn, U_AM, U_AC) * w_o;      // :345
                         // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
-                        carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
+                        carrier = (quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
                     }
                 }
                 float pressure = atten * amp * fd * carrier;                           // :348
                 if (ci != 0xffffffffu) {
+                    if (EMIT) pressure *= w_ray;  // the weight of the path's primary ray (DESIGN D15)
 #ifdef PBRT_ABLATE_US_AGG  // diagnostic builds only
                     atomicAdd(&a.channel[ci], pressure);
 #else
@@ -365,7 +401,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                 d = normalize(new_dir);                                                // :358-359
                 o = offset_origin(si.p, si.n, d);
                 bool surv;
-                if (a.p.quirks & PBRT_USQ_SIGNED_RR) {                                 // Dr.Jit variant :219-224
+                if (quirks & PBRT_USQ_SIGNED_RR) {                                 // Dr.Jit variant :219-224
                     const float rr_prob = fminf(atten * amp, 1.0f);
                     surv = u.w < rr_prob;
                     atten = surv ? atten / rr_prob : 0.0f;
@@ -401,8 +437,9 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
         }
     }
     if (survive) {
-        const uint32_t v4 = us_state_voff(base + out_off + off + prefix);
+        const uint32_t v4 = us_state_voff(base + out_off + off + prefix, ROWS);
         constexpr uint32_t row = STATE_ROW_BYTES;
+        if (EMIT) bst(r_out, v4 + 11 * row, 0, w_ray);
         bst(r_out, v4 + 0 * row, 0, o.x);
         bst(r_out, v4 + 1 * row, 0, o.y);
         bst(r_out, v4 + 2 * row, 0, o.z);
@@ -454,6 +491,36 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
 #undef U_INVC
 #undef U_FS
 #undef U_MAXLEN
+
+// PBRT_US_PRIMARY_EMITTER, brute-force scenes: the primary rays of a pass written into the (twelve-row) path state, so that
+// k_us_bounce<false, ., EMIT> can walk every bounce from depth 0.  Drawing the ray inside the first-bounce instance instead
+// (k_us_bounce<true, ., EMIT>: no state traffic at depth 0) costs that kernel 17 spilled VGPRs at its 80-register budget -- the
+// emitter's sincos on top of the table-less first bounce -- and is the slower of the two (profiles/r05_us_emitter_ab.txt);
+// PBRT_US_EMIT_FUSED=1 selects it.
+__global__ __launch_bounds__(256) void k_us_emit_init(const UsArgs a, uint32_t region, uint32_t n_regions) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_regions) a.seg_out[i] = a.n_paths > i * region ? min(a.n_paths - i * region, region) : 0u;
+    if (i >= a.n_paths) return;
+    const uint32_t ray_id = udiv_fast(i, a.div_ppr);
+    const uint32_t ang = udiv_fast(ray_id, a.div_ne), el = ray_id - ang * a.p.n_elements;
+    V3 o, d;
+    float tof;
+    const float w_ray = us_emitter_primary(a.p, a.p.sensor_to_world, ray_id, a.path_first + (i - ray_id * a.ppr_pass), ang, el, a.seed, &o, &d, &tof);
+    float *st = a.out + us_state_voff(i, US_N_STATE + 1u) / 4u;
+    constexpr uint32_t row = STATE_ROW_BYTES / 4u;
+    st[0 * row] = o.x;
+    st[1 * row] = o.y;
+    st[2 * row] = o.z;
+    st[3 * row] = d.x;
+    st[4 * row] = d.y;
+    st[5 * row] = d.z;
+    st[6 * row] = 1.0f;   // amp   :276
+    st[7 * row] = 1.0f;   // atten :277
+    st[8 * row] = tof;    // the ray's emission time (CustomEmmitter.py:93-94)
+    st[9 * row] = 0.0f;   // geo_len
+    st[10 * row] = __uint_as_float(i);
+    st[11 * row] = w_ray;
+}
 
 // First-bounce tables, one thread per (ray, receive element): the primary ray, its closest hit, and the occlusion test
 // towards the element -- the statements of k_us_bounce<FIRST> up to `visible`, once instead of once per path.

@@ -16,7 +16,7 @@
 // (ray, receive element) record, visibility included, and deposits at once.
 //
 // Path state, 64 B in float4 planes:  q0 = (o, amp)  q1 = (d, atten)  q2 = (tof, geo_len, home, pending channel index | ~0)
-//                                     q3 = (pending pressure, -, -, visibility: written 0 here, set by k_trace)
+//                                     q3 = (pending pressure, weight of the primary ray, -, visibility: written 0 here, set by k_trace)
 // Occlusion-ray records as in kernels_wavefront.h: q0 = (origin, tmax = inf), q1 = (direction, dest); records of ended paths also
 // q2 = (pressure, channel index, -, visibility).
 #pragma once
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256) void k_us_init_wf(const UsArgs a, float4 *st, 
     const uint32_t ang = udiv_fast(ray_id, a.div_ne), el = ray_id - ang * a.p.n_elements;
     V3 o = xf_point(a.p.sensor_to_world, v3(a.elem_x[el], 0.0f, 0.0f));
     V3 d = v3(a.dir0[3 * ang], a.dir0[3 * ang + 1], a.dir0[3 * ang + 2]);
-    float amp = 1.0f, tof = 0.0f;
+    float tof = 0.0f, w_ray = 1.0f;
     if (a.p.primary == PBRT_US_PRIMARY_EMITTER)  // the path's own ray from CustomEmitter.sample_ray (kernels_us.h us_emitter_primary)
-        us_emitter_primary(a.p, a.p.sensor_to_world, ray_id, a.path_first + (i - ray_id * a.ppr_pass), ang, el, a.seed, &o, &d, &amp, &tof);
+        w_ray = us_emitter_primary(a.p, a.p.sensor_to_world, ray_id, a.path_first + (i - ray_id * a.ppr_pass), ang, el, a.seed, &o, &d, &tof);
     const size_t cp = a.cap;
-    const float4 q0 = {o.x, o.y, o.z, amp}, q1 = {d.x, d.y, d.z, 1.0f}, q2 = {tof, 0.0f, __uint_as_float(i), __uint_as_float(0xffffffffu)},
-                 q3 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float4 q0 = {o.x, o.y, o.z, 1.0f}, q1 = {d.x, d.y, d.z, 1.0f}, q2 = {tof, 0.0f, __uint_as_float(i), __uint_as_float(0xffffffffu)},
+                 q3 = {0.0f, w_ray, 0.0f, 0.0f};  // q3.y: the weight of the path's primary ray (1 for the integrator's own)
     st[i] = q0;
     st[cp + i] = q1;
     st[2u * cp + i] = q2;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
         list_n -= take;
         bool survive = false, pend = false;
         V3 o = {0, 0, 0}, d = {0, 0, 1}, so = {0, 0, 0}, sdir = {0, 0, 1};
-        float amp = 1.0f, atten = 1.0f, tof = 0.0f, geo_len = 0.0f, pressure = 0.0f;
+        float amp = 1.0f, atten = 1.0f, tof = 0.0f, geo_len = 0.0f, pressure = 0.0f, w_ray = 1.0f;
         uint32_t home = 0, ci = 0xffffffffu;
         if (act) {
             const uint32_t s = wlist[wid][list_n + lane];
@@ -188,6 +188,9 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
                 h.v = fh.z;
             } else {
                 const float4 q0 = w.st_in[base + s], q1 = w.st_in[cp + base + s], q2 = w.st_in[2u * cp + base + s];
+                // the weight of the path's primary ray rides in q3.y (k_us_init_wf); it is 1 unless the rays come from the emitter, so
+                // only that mode reads it
+                if (a.p.primary == PBRT_US_PRIMARY_EMITTER) w_ray = w.st_in[3u * cp + base + s].y;
                 o = {q0.x, q0.y, q0.z};
                 amp = q0.w;
                 d = {q1.x, q1.y, q1.z};
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
                         carrier = (a.p.quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
                     }
                 }
-                pressure = atten * amp * fd * carrier;                                    // :348
+                pressure = atten * amp * fd * carrier * w_ray;                            // :348 (x 1, or the emitter ray's weight: D15)
                 if (ci != 0xffffffffu) {
                     if (TAB) {
                         deposit(ci, pressure);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_us_
         if (survive) {
             const float4 q0 = {o.x, o.y, o.z, amp}, q1 = {d.x, d.y, d.z, atten},
                          q2 = {tof, geo_len, __uint_as_float(home), __uint_as_float(shd_live ? ci : 0xffffffffu)},
-                         q3 = {shd_live ? pressure : 0.0f, 0.0f, 0.0f, 0.0f};
+                         q3 = {shd_live ? pressure : 0.0f, w_ray, 0.0f, 0.0f};
             w.st_out[out_slot] = q0;
             w.st_out[cp + out_slot] = q1;
             w.st_out[2u * cp + out_slot] = q2;

@@ -1639,16 +1639,51 @@ int pbrt_us_tx_delays(const pbrt_us_params *p, float *tx) {
 
 }  // extern "C"
 
+// which instance of k_us_bounce: the switches of the library's default (with / without the carrier) are compiled in, any other set
+// -- and PBRT_US_GENERIC_KERNEL=1 -- takes the instance that reads them at run time (kernels_us.h)
+static uint32_t us_kernel_quirks(const UsArgs &a) {
+    const char *gen = getenv("PBRT_US_GENERIC_KERNEL");  // read per launch: a test runs both instances in one process
+    if (gen && atoi(gen) != 0) return US_Q_RUNTIME;
+    const uint32_t host_only = PBRT_USQ_NO_FIRST_TABLES | PBRT_USQ_NO_FUSED_BOUNCES;  // decided on the host: tables null, a.fuse 0
+    const uint32_t q = a.p.quirks & ~host_only;
+    return (q == PBRT_USQ_REFERENCE || q == (PBRT_USQ_REFERENCE | PBRT_USQ_NO_CARRIER)) ? q : US_Q_RUNTIME;
+}
+template <bool FIRST, int ACCEL, bool EMIT>
+static void launch_us_instance(const UsArgs &a, uint32_t nseg, uint32_t threads, size_t lds, hipStream_t st) {
+    const uint32_t q = us_kernel_quirks(a);
+    const int tab = !FIRST ? -1 : (a.first_hit && a.first_rx) ? 1 : (!a.first_hit && !a.first_rx) ? 0 : -1;
+#define US_LAUNCH(QQ, TT) hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL, EMIT, QQ, TT>), dim3(nseg), dim3(threads), lds, st, a)
+    if constexpr (ACCEL == ACCEL_K_BRUTE) {  // the kernels of BASELINE config 3 (both readings) and of the reference's own loop
+        if (q != US_Q_RUNTIME && (tab >= 0 || !FIRST)) {
+            const bool carrier = q == PBRT_USQ_REFERENCE;
+            if constexpr (!FIRST) {
+                if (carrier) US_LAUNCH(PBRT_USQ_REFERENCE, -1); else US_LAUNCH(PBRT_USQ_REFERENCE | PBRT_USQ_NO_CARRIER, -1);
+            } else if constexpr (EMIT) {  // (emitter rays: never any tables)
+                if (carrier) US_LAUNCH(PBRT_USQ_REFERENCE, 0); else US_LAUNCH(PBRT_USQ_REFERENCE | PBRT_USQ_NO_CARRIER, 0);
+            } else {
+                if (tab == 1) {
+                    if (carrier) US_LAUNCH(PBRT_USQ_REFERENCE, 1); else US_LAUNCH(PBRT_USQ_REFERENCE | PBRT_USQ_NO_CARRIER, 1);
+                } else {
+                    if (carrier) US_LAUNCH(PBRT_USQ_REFERENCE, 0); else US_LAUNCH(PBRT_USQ_REFERENCE | PBRT_USQ_NO_CARRIER, 0);
+                }
+            }
+            return;
+        }
+    }
+    US_LAUNCH(US_Q_RUNTIME, -1);
+#undef US_LAUNCH
+}
+
 template <bool FIRST>
 static int launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     hipStream_t st = s->ctx->stream;
-    if (FIRST && a.p.primary == PBRT_US_PRIMARY_EMITTER) {  // every path draws its primary ray from CustomEmitter.sample_ray
+    if (a.p.primary == PBRT_US_PRIMARY_EMITTER) {  // primary rays from CustomEmitter.sample_ray, echoes times the ray's weight
         switch (s->accel_kernel) {
             case ACCEL_K_BRUTE:
-                hipLaunchKernelGGL((k_us_bounce<true, ACCEL_K_BRUTE, true>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+                launch_us_instance<FIRST, ACCEL_K_BRUTE, true>(a, nseg, SEG_BRUTE, 0, st);
                 return PBRT_OK;
             case ACCEL_K_BRUTE_BIG:
-                hipLaunchKernelGGL((k_us_bounce<true, ACCEL_K_BRUTE_BIG, true>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+                launch_us_instance<FIRST, ACCEL_K_BRUTE_BIG, true>(a, nseg, SEG_BRUTE, 0, st);
                 return PBRT_OK;
             default:
                 return s->ctx->fail(PBRT_E_UNSUPPORTED, "launch_us: emitter primary rays on BVH scenes run as streams (us_wf_pass)");
@@ -1656,17 +1691,17 @@ static int launch_us(pbrt_scene *s, const UsArgs &a, uint32_t nseg) {
     }
     switch (s->accel_kernel) {
         case ACCEL_K_BRUTE:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            launch_us_instance<FIRST, ACCEL_K_BRUTE, false>(a, nseg, SEG_BRUTE, 0, st);
             break;
         case ACCEL_K_BRUTE_BIG:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BRUTE_BIG>), dim3(nseg), dim3(SEG_BRUTE), 0, st, a);
+            launch_us_instance<FIRST, ACCEL_K_BRUTE_BIG, false>(a, nseg, SEG_BRUTE, 0, st);
             break;
 #ifdef PBRT_DIAG  // the fused ultrasound bounce on BVH scenes (PBRT_US_FUSED_BVH=1): diagnostic build only
         case ACCEL_K_BVH_GLOBAL:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_GLOBAL>), dim3(nseg), dim3(SEG_BVH), 0, st, a);
+            launch_us_instance<FIRST, ACCEL_K_BVH_GLOBAL, false>(a, nseg, SEG_BVH, 0, st);
             break;
         default:
-            hipLaunchKernelGGL((k_us_bounce<FIRST, ACCEL_K_BVH_LDS>), dim3(nseg), dim3(SEG_BVH), s->lds_bytes, st, a);
+            launch_us_instance<FIRST, ACCEL_K_BVH_LDS, false>(a, nseg, SEG_BVH, s->lds_bytes, st);
             break;
 #else
         default:  // BVH scenes run k_trace / k_us_shade (us_wf_pass)
@@ -1871,6 +1906,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
+    const char *e_fused = getenv("PBRT_US_EMIT_FUSED");  // A/B: draw the emitter ray inside the first-bounce kernel
+    const bool emit_fused = e_fused && atoi(e_fused) != 0;
     if (emit)  // the ray's own emission time rides in its time of flight (CustomEmmitter.py:93-94); t0 of :329 is 0
         HIPCHK(c, hipMemsetAsync(d_tx, 0, (size_t)n_rays * 4, st));
     else
@@ -1961,7 +1998,20 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
                 n_ev += 2;
                 HIPCHK(c, hipEventRecord(e0, st));
             }
-            if ((rc = depth == 0 ? launch_us<true>(s, a, nseg_pass) : launch_us<false>(s, a, nseg_pass)) != 0) return rc;
+            bool first_kernel = depth == 0;
+            if (depth == 0 && emit && !emit_fused) {
+                // emitter rays: the primary rays into the state (k_us_emit_init writes a.out / a.seg_out), then the later-bounce
+                // instance from depth 0
+                hipLaunchKernelGGL(k_us_emit_init, dim3(div_up(std::max(a.n_paths, nseg_pass), 256)), dim3(256), 0, st, a, REGION, nseg_pass);
+                std::swap(in, out);
+                std::swap(sin, sout);
+                a.in = in;
+                a.out = out;
+                a.seg_in = sin;
+                a.seg_out = sout;
+                first_kernel = false;
+            }
+            if ((rc = first_kernel ? launch_us<true>(s, a, nseg_pass) : launch_us<false>(s, a, nseg_pass)) != 0) return rc;
             HIPCHK(c, hipGetLastError());
             ++launches;
             if (a.fuse) break;  // that launch walked every bounce (kernels_us.h)

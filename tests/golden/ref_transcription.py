@@ -328,8 +328,10 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
     """draws(depth) -> (u_recv, s1, s2, u_rr): the four uniforms of one bounce (:319, :337, :365).
     primary: None = the integrator's own ray (:264-273); else (o, d, ray time, weight) of CustomEmitter.sample_ray in the
     transducer's frame (emitter_sample_ray below): the path starts there -- origin and direction taken to the world like :273,
-    the ray's time as its initial time of flight (t0 = 0), its weight as its initial amplitude (the library's
-    PBRT_US_PRIMARY_EMITTER; the reference itself never connects its emitter to its integrator).
+    the ray's time as its initial time of flight (t0 = 0), its weight as a factor of every echo the path deposits -- Mitsuba's
+    SamplingIntegrator::render_sample multiplies what Integrator.sample returns by the weight of the sampled ray, the path's own
+    amplitude still starts at 1 (:276) -- (the library's PBRT_US_PRIMARY_EMITTER; the reference itself never connects its emitter
+    to its integrator).
     variant "scalar": _trace_single_ray of simulate_acquisition_parallel (:262-376, what USMain.py calls);
     variant "drjit": the body of simulate_acquisition's dr.while_loop (:137-226), where it differs -- the draws are taken
     while the loop body is TRACED (llvm_ad_mono, USMain.py:12), i.e. once per ray: every bounce sees draws(0) (:153,173-174,
@@ -348,10 +350,11 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
     direction = vec(math.sin(a_rad), 0.0, math.cos(a_rad))                                          # :271
     ray_o, ray_d = R @ origin + tr, normalize(R @ direction)                                        # :273
     amp, atten, tof, geo_len, depth, active = 1.0, 1.0, 0.0, 0.0, 0, True                           # :276-281
+    ray_weight = 1.0
     if primary is not None:
         e_o, e_d, e_time, e_weight = primary                                                        # CustomEmmitter.py:100-107
         ray_o, ray_d = R @ np.asarray(e_o, dtype=np.float64) + tr, normalize(R @ np.asarray(e_d, dtype=np.float64))
-        amp, tof, t0 = float(e_weight), float(e_time), 0.0
+        tof, t0, ray_weight = float(e_time), 0.0, float(e_weight)
     trans_normal_world = normalize(R @ vec(0.0, 0.0, 1.0))                                          # :292, :369
     alpha_m, alpha_c = math.radians(P["main_beam_angle"]), math.radians(P["cutoff_angle"])          # :345
     out = []
@@ -389,7 +392,7 @@ def us_trace_single_ray(shapes, sensor_T, P, angle_idx, elem_idx, draws, variant
         w_i = 1.0 if alpha <= alpha_m else (mid_cond if alpha <= alpha_c else 0.0)                  # :299-302
         w_o = float(ray_d @ n_sh) / num_rays                                                        # :286-287 (si.sh_frame.n, :345)
         fd = w_i * w_o
-        envelope = atten * amp * fd
+        envelope = atten * amp * fd * ray_weight      # (ray_weight: 1, or the emitter ray's -- applied to what the loop deposits)
         pressure_scalar = envelope * math.sin(phase)                                                # :348
         t_float = total_time * fs_scalar                                                            # :351
         t_idx = int(round(t_float))                                                                 # :352 (half to even)

@@ -360,3 +360,23 @@ def test_emitter_primary_rays_on_a_mesh_phantom_and_their_refusals(mi, ob, capi)
     sc._emitters.clear()
     with pytest.raises(ValueError, match="ultrasound_emitter"):
         ui.us_params(sc)
+
+
+@pytest.mark.parametrize("scene,ppr", [("us_sphere_box.xml", 128), ("us_sphere_box.xml", 24), ("us_plate.xml", 200)])
+def test_specialised_and_generic_bounce_kernels_agree(mi, capi, monkeypatch, scene, ppr):
+    """k_us_bounce exists with the library's default switches compiled in (PBRT_USQ_REFERENCE, with / without the carrier; with /
+    without the first-bounce tables) and as a generic instance that reads pbrt_us_params.quirks at run time (any other set).
+    PBRT_US_GENERIC_KERNEL=1 sends the default set through the generic instance: same segments, same echoes."""
+    sc = mi.load_file(scene_path(scene), paths_per_ray=ppr, seed=21)
+    ui = sc.integrator()
+    ctx = mi.default_context()
+    for q in (ui.quirks, ui.quirks | capi.USQ_NO_CARRIER, ui.quirks | capi.USQ_NO_FIRST_TABLES):
+        monkeypatch.delenv("PBRT_US_GENERIC_KERNEL", raising=False)
+        fast = ui._acquire(sc, q, pulse=False)
+        st_fast = ctx.stats()
+        monkeypatch.setenv("PBRT_US_GENERIC_KERNEL", "1")
+        gen = ui._acquire(sc, q, pulse=False)
+        st_gen = ctx.stats()
+        monkeypatch.delenv("PBRT_US_GENERIC_KERNEL")
+        assert st_fast["segments"] == st_gen["segments"] > 0 and st_fast["live"] == st_gen["live"]
+        assert np.array_equal(fast != 0, gen != 0) and np.allclose(fast, gen, rtol=2e-5, atol=1e-7 * np.abs(gen).max())

@@ -16,8 +16,8 @@
  *  - *_dev variants take DEVICE pointers (e.g. torch tensor data_ptr(), or pbrt_dev_alloc) and keep data in HBM.
  *  - one pbrt_ctx per device; calls on a ctx are not re-entrant; calls are synchronous on return (the ctx
  *    stream has been synchronised) EXCEPT the image-formation *_dev entry points of ABI 5
- *    (pbrt_das_beamform_dev, pbrt_envelope_dev, pbrt_log_compress_dev, pbrt_us_apply_pulse_dev) and
- *    pbrt_dev_upload: those queue their work on the ctx stream, in call order behind everything queued before,
+ *    (pbrt_das_beamform_dev, pbrt_envelope_dev, pbrt_log_compress_dev, pbrt_us_apply_pulse_dev), pbrt_us_acquire_queue_dev,
+ *    pbrt_scene_update_material and pbrt_dev_upload: those queue their work on the ctx stream, in call order behind everything queued before,
  *    and return; pbrt_ctx_synchronize / pbrt_dev_download wait for it.  A caller that hands in memory of
  *    another runtime's stream (a torch tensor) orders the two streams itself.
  *  - the caller owns every buffer it passes; the library owns device memory behind the opaque
@@ -481,13 +481,22 @@ int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples,
  * USMain.py:92-252 runs acquisition -> DAS -> envelope -> log compression 51 times per script (:260, :279-283).  With the
  * host-pointer forms above every step crosses PCIe twice (the 12.8 MB channel buffer up, an image down).  The *_dev forms take
  * device pointers, queue their kernels on the context's stream and return without synchronising:
- *     pbrt_us_acquire_dev(scene, ..., d_channel, tx)            (synchronous, as before)
+ *     pbrt_us_acquire_queue_dev(scene, ..., d_channel, tx)      queued (pbrt_us_acquire_dev: the same, and waits)
  *     [pbrt_us_apply_pulse_dev(ctx, ..., d_channel, d_rf)]       pulse_model = "gaussian" only
  *     pbrt_das_beamform_dev(ctx, &das, d_rf, d_tx, d_elem_x, d_x, d_z, d_bf)
  *     pbrt_envelope_dev(ctx, nx, nz, d_bf, d_env)
  *     pbrt_log_compress_dev(ctx, nx * nz, d_env, 60, d_img)
  *     pbrt_dev_download(ctx, img, d_img, nx * nz * 4)            the ONE copy to the host; waits for the stream
  * Same kernels, same results bit for bit as the host-pointer forms (which stage their arguments and call the same code). */
+/* pbrt_us_acquire_dev without the wait: the acquisition is queued on the context's stream and the call returns; the channel
+ * buffer is complete for whatever is queued behind it (the image-formation *_dev calls) and for the host after
+ * pbrt_ctx_synchronize / pbrt_dev_download.  Its statistics -- and the error of a tripped traversal guard, PBRT_E_DEVICE --
+ * arrive with the next call on the context that waits for the stream or starts other work (pbrt_get_stats, pbrt_ctx_synchronize,
+ * pbrt_dev_download, the next acquisition or render ...): that call finishes the queued acquisition first and returns its error.
+ * tx_delays (host, may be NULL) is filled before the call returns. */
+int pbrt_us_acquire_queue_dev(pbrt_scene *scene, const pbrt_us_params *p, uint32_t seed, uint32_t paths_per_ray,
+                              uint32_t path_offset, uint32_t norm_paths, void *d_channel_buf, float *tx_delays);
+
 /* replaces: ultraspy DelayAndSum.beamform(d_data, scan) (USMain.py:204), data and tables in HBM.  All pointers are device
  * pointers: d_data [n_angles][n_elements][time_samples], d_tx_delays [n_angles][n_elements], d_elem_x [n_elements],
  * d_x [nx], d_z [nz], d_out [nx][nz]. */

@@ -175,6 +175,7 @@ SIGNATURES = {
                                          C.c_uint32, _F]),
     "pbrt_us_acquire": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _F, _F]),
     "pbrt_us_acquire_dev": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _F]),
+    "pbrt_us_acquire_queue_dev": (C.c_int, [_P, C.POINTER(UsParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P, _F]),
     "pbrt_ray_intersect": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F, _F, _F, _F]),
     "pbrt_ray_test": (C.c_int, [_P, C.c_uint32, _F, _F, _F, _F]),
     "pbrt_bsdf_sample": (C.c_int, [_P, C.POINTER(Material), C.c_uint32, C.c_uint32, _F, _F, _F, _F, _F, _F, _F, _F, _F, _F]),

@@ -272,7 +272,8 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
         plan.key = key
         integ._render_plan = plan
     t0 = _time.perf_counter()
-    integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed, out_dev=plan.d_channel.ptr, pulse=False)  # :99
+    integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed, out_dev=plan.d_channel.ptr, pulse=False,
+                   queue=True)                                                                          # :99 (queued, not waited for)
     t1 = _time.perf_counter()
     delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)                 # :121
     if plan.tx_host is None or not np.array_equal(plan.tx_host, delays):

@@ -250,20 +250,22 @@ __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params
 // h[N - n] = -h[n].  That is N^2 real multiply-adds per column where round 1's two O(N^2) DFT passes with complex twiddles
 // were 4 N^2 plus an LDS read with a data-dependent bank per operand; the taps h[n - m] of neighbouring outputs are
 // neighbouring LDS words (ds_read_b128, conflict-free), the column is a broadcast read, and a thread carries four outputs
-// over four inputs per trip: 16 multiply-adds per three 16-byte LDS reads.  Taps in f64 (sincospi), sums in f32.
+// over four inputs per trip: 16 multiply-adds per three 16-byte LDS reads.  Taps in f64 (sincospi, k_hilbert_taps), sums in f32.
 // One 256-thread workgroup per column, N <= ENV_MAX_N.  LDS: column [Np] + taps [2 Np + 8], Np = N rounded up to 4.
 #define ENV_MAX_N 4096
-__global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *__restrict__ rf, float *__restrict__ env) {
-    extern __shared__ __attribute__((aligned(16))) float lds_env[];
-    const uint32_t N = nz, Np = (N + 3u) & ~3u, C = Np + 4u, G = 2u * Np + 8u, col = blockIdx.x;
-    float *xs = lds_env;      // [Np], zero beyond N
-    float *g = lds_env + Np;  // g[C + k] = h[k] for 0 < k < N, -h[-k] for -N < k < 0, 0 elsewhere
-    for (uint32_t j = threadIdx.x; j < Np; j += blockDim.x) xs[j] = j < N ? rf[(size_t)col * N + j] : 0.0f;
-    for (uint32_t j = threadIdx.x; j < G; j += blockDim.x) g[j] = 0.0f;
-    __syncthreads();
-    const double inv_n = 1.0 / (double)N;
-    for (uint32_t n = 1u + threadIdx.x; n < N; n += blockDim.x) {
-        double sn, cs, h;
+// the tap table of a column length N, g[C + k] = h[k] for 0 < k < N, -h[-k] for -N < k < 0, 0 elsewhere (C = Np + 4, 2 Np + 8 entries):
+// computed once per N and kept by the context -- every column of every image of a loop uses the same one, and the f64 sincospi and
+// division per tap were most of the kernel when each workgroup made its own copy (47 -> 2x us at 1040 columns of 638)
+__global__ __launch_bounds__(256) void k_hilbert_taps(uint32_t N, float *__restrict__ g) {
+    const uint32_t Np = (N + 3u) & ~3u, C = Np + 4u, G = 2u * Np + 8u;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= G) return;
+    const int32_t k = (int32_t)j - (int32_t)C;
+    const uint32_t n = (uint32_t)(k < 0 ? -k : k);
+    double h = 0.0;
+    if (n >= 1u && n < N) {
+        const double inv_n = 1.0 / (double)N;
+        double sn, cs;
         if ((N & 1u) == 0u) {
             sincospi((double)n * inv_n, &sn, &cs);
             h = (n & 1u) ? 2.0 * inv_n * cs / sn : 0.0;
@@ -271,31 +273,56 @@ __global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *_
             sincospi(0.5 * (double)n * inv_n, &sn, &cs);
             h = (n & 1u) ? inv_n * cs / sn : -inv_n * sn / cs;
         }
-        g[C + n] = (float)h;
-        g[C - n] = (float)-h;
     }
+    g[j] = (float)(k < 0 ? -h : h);
+}
+__global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *__restrict__ rf, const float *__restrict__ taps,
+                                                     float *__restrict__ env) {
+    extern __shared__ __attribute__((aligned(16))) float lds_env[];
+    const uint32_t N = nz, Np = (N + 3u) & ~3u, C = Np + 4u, G = 2u * Np + 8u, col = blockIdx.x;
+    float *xs = lds_env;      // [Np], zero beyond N (the tail of the column, and the outputs' own samples)
+    float *g = lds_env + Np;  // the tap table
+    const float *xr = rf + (size_t)col * N;
+    for (uint32_t j = threadIdx.x; j < Np; j += blockDim.x) xs[j] = j < N ? xr[j] : 0.0f;
+    for (uint32_t j = threadIdx.x; j < G; j += blockDim.x) g[j] = taps[j];
     __syncthreads();
+    // The kernel is bound by LDS reads, not by its multiply-adds: three 16-byte reads per 16 of them (the four samples as a broadcast,
+    // the tap window as two quads) kept the LDS of a CU busy for 3 x as long as its SIMDs.  The window of trip m + 4 starts four taps
+    // below the window of trip m, so its upper quad IS the lower quad of the trip before: one tap read per trip.  And the four samples
+    // are the same for every lane of the workgroup: read from the column in global memory with a uniform address they are scalar loads
+    // (s_load_dwordx4 through the scalar cache) and enter the multiply-adds as scalar operands: no LDS read at all.  48 -> 2x us.
     for (uint32_t n0 = 4u * threadIdx.x; n0 < Np; n0 += 4u * blockDim.x) {
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         const float *gp = g + (C + n0 - 4u);
-        for (uint32_t m = 0; m < Np; m += 4u) {
-            const float4 xv = *reinterpret_cast<const float4 *>(xs + m);
-            const float4 wa = *reinterpret_cast<const float4 *>(gp - m), wb = *reinterpret_cast<const float4 *>(gp - m + 4);
-            // output n0 + j, input m + i: tap index (j - i) + 4 of the window w = (wa, wb)
-            a0 = fma_(xv.x, wb.x, a0); a0 = fma_(xv.y, wa.w, a0); a0 = fma_(xv.z, wa.z, a0); a0 = fma_(xv.w, wa.y, a0);
-            a1 = fma_(xv.x, wb.y, a1); a1 = fma_(xv.y, wb.x, a1); a1 = fma_(xv.z, wa.w, a1); a1 = fma_(xv.w, wa.z, a1);
-            a2 = fma_(xv.x, wb.z, a2); a2 = fma_(xv.y, wb.y, a2); a2 = fma_(xv.z, wb.x, a2); a2 = fma_(xv.w, wa.w, a2);
-            a3 = fma_(xv.x, wb.w, a3); a3 = fma_(xv.y, wb.z, a3); a3 = fma_(xv.z, wb.y, a3); a3 = fma_(xv.w, wb.x, a3);
-        }
+        float4 wb = *reinterpret_cast<const float4 *>(gp + 4);
+        const uint32_t full = N & ~3u;
+#define ENV_TRIP(x0, x1, x2, x3)                                                                                  \
+    {                                                                                                             \
+        const float4 wa = *reinterpret_cast<const float4 *>(gp - m);                                              \
+        /* output n0 + j, input m + i: tap index (j - i) + 4 of the window w = (wa, wb) */                        \
+        a0 = fma_(x0, wb.x, a0); a0 = fma_(x1, wa.w, a0); a0 = fma_(x2, wa.z, a0); a0 = fma_(x3, wa.y, a0);       \
+        a1 = fma_(x0, wb.y, a1); a1 = fma_(x1, wb.x, a1); a1 = fma_(x2, wa.w, a1); a1 = fma_(x3, wa.z, a1);       \
+        a2 = fma_(x0, wb.z, a2); a2 = fma_(x1, wb.y, a2); a2 = fma_(x2, wb.x, a2); a2 = fma_(x3, wa.w, a2);       \
+        a3 = fma_(x0, wb.w, a3); a3 = fma_(x1, wb.z, a3); a3 = fma_(x2, wb.y, a3); a3 = fma_(x3, wb.x, a3);       \
+        wb = wa;                                                                                                  \
+    }
+        uint32_t m = 0;
+        // the column itself, through the scalar cache; four trips per round so that sixteen scalar loads share one wait
+#pragma unroll 4
+        for (; m < full; m += 4u) ENV_TRIP(xr[m], xr[m + 1u], xr[m + 2u], xr[m + 3u])
+        if (m < Np) ENV_TRIP(xs[m], xs[m + 1u], xs[m + 2u], xs[m + 3u])  // the last, partial quad: zero-padded copy in LDS
+#undef ENV_TRIP
         const float xh[4] = {a0, a1, a2, a3};
         for (uint32_t j = 0; j < 4u; ++j)
             if (n0 + j < N) env[(size_t)col * N + n0 + j] = sqrtf(fma_(xs[n0 + j], xs[n0 + j], xh[j] * xh[j]));
     }
 }
 
-// Log compression (USMain.py:210-218).  Pass 1: maximum of the (non-negative) envelope; the order-preserving
-// uint view of non-negative floats lets atomicMax do it.  Pass 2: map.
-__global__ __launch_bounds__(256) void k_env_max(uint32_t n, const float *__restrict__ env, uint32_t *mx) {
+// Log compression (USMain.py:210-218).  Pass 1: every block leaves the maximum of its share of the (non-negative) envelope in its own
+// word; pass 2: every block folds those <= ENV_MAX_BLOCKS words and maps its pixels.  (Round 1 had 1024 blocks meet in one atomicMax on
+// a word the host had to clear first: 14 us for 2.6 MB, most of it the same-word atomics, plus a fill command per call.)
+#define ENV_MAX_BLOCKS 256u
+__global__ __launch_bounds__(256) void k_env_max(uint32_t n, const float *__restrict__ env, float *__restrict__ block_max) {
     __shared__ float part[256];
     float m = 0.0f;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, env[i]);
@@ -305,13 +332,20 @@ __global__ __launch_bounds__(256) void k_env_max(uint32_t n, const float *__rest
         if (threadIdx.x < w) part[threadIdx.x] = fmaxf(part[threadIdx.x], part[threadIdx.x + w]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) atomicMax(mx, __float_as_uint(fmaxf(part[0], 0.0f)));
+    if (threadIdx.x == 0) block_max[blockIdx.x] = fmaxf(part[0], 0.0f);
 }
-__global__ __launch_bounds__(256) void k_log_compress(uint32_t n, const float *__restrict__ env, const uint32_t *mx, float dr,
-                                                      float *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_log_compress(uint32_t n, const float *__restrict__ env, const float *__restrict__ block_max,
+                                                      uint32_t n_blocks, float dr, float *__restrict__ out) {
+    __shared__ float part[256];
+    part[threadIdx.x] = threadIdx.x < n_blocks ? block_max[threadIdx.x] : 0.0f;
+    __syncthreads();
+    for (uint32_t w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] = fmaxf(part[threadIdx.x], part[threadIdx.x + w]);
+        __syncthreads();
+    }
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float max_db = 20.0f * log10f(__uint_as_float(*mx) + 1e-12f);
+    const float max_db = 20.0f * log10f(part[0] + 1e-12f);
     const float min_db = max_db - dr;
     float db = 20.0f * log10f(env[i] + 1e-12f);
     db = fminf(fmaxf(db, min_db), max_db);

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
     uint32_t s_hint = 0;    // wave-uniform: segment of the wave's last fetch (queue indices only grow)
     uint32_t turns = 0;     // wave-uniform (kept in a scalar register by the readfirstlane at its updates)
 #ifdef PBRT_WF_PROBE
-    unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] walk trips [1] lanes in them [2] leaf trips [3] lanes [4] main trips [5] rays fetched [6] lanes with a ray per main trip
+    unsigned long long probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [0] walk trips [1] lanes in them [2] leaf trips [3] lanes [4] main trips [5] rays fetched [6] lanes with a ray per main trip [7] lanes holding a leaf, summed over the walk trips
 #endif
     for (;;) {
         if (turns > WF_GUARD_TURNS) {  // (uniform: the whole wave reports and leaves)
@@ -306,9 +306,14 @@ __global__ __launch_bounds__(1024, WF_TRACE_WAVES_PER_EU) void k_trace(const WfA
         const uint32_t walk_min = q_empty ? 1u : WF_WALK_MIN;  // wave-uniform
         for (;;) {
             const bool walking = (int32_t)c.cur >= 0;
-            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < walk_min) break;
+            const uint32_t n_walk = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking));
+            if (n_walk < walk_min) break;
+#ifdef WF_WALK_ADAPT  // A/B (round 5): also stop walking once the lanes that wait with a leaf outnumber the walkers WF_WALK_ADAPT : 1
+            if (n_walk * WF_WALK_ADAPT < (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c.cur - 0x80000000u < 0x7ffffffeu))) break;
+#endif
             WF_PROBE(0, 1);
             WF_PROBE(1, __builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)));
+            WF_PROBE(7, __builtin_popcountll(__builtin_amdgcn_ballot_w64(c.cur - 0x80000000u < 0x7ffffffeu)));  // lanes that hold a leaf through this visit
             turns = (uint32_t)__builtin_amdgcn_readfirstlane((int)(turns + WF_WALK_UNROLL));
             if (turns > WF_GUARD_TURNS) break;  // (the main loop's guard reports)
             if (walking) bvh_visit(tr, st, c, ovf, br, best);
@@ -574,6 +579,11 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
     constexpr int NCH = WF_SHADE_CHUNKS;  // chunks of 64 hit indices a wave reads per step
     // per wave: the paths that hit something and wait for a full wave -- slot within the region, and the primitive that was hit
     __shared__ uint32_t wlist[W][64 * (NCH + 1)], wprim[W][64 * (NCH + 1)];
+    // ... and (bounces >= 1) its radiance so far with the pending shadow contribution folded in, and its home: the chunk phase streams
+    // the L / A / B planes of EVERY path of the chunk anyway (a path that missed needs them to end), so a path that hit keeps what
+    // they amount to -- L = fma(A, B, L), home -- on the list instead of gathering the three planes again in the shading step:
+    // 48 of the 96 gathered bytes per hit, at 128-byte lines for 16-byte records (round 4: traffic 1.25 x the model)
+    __shared__ float4 wlh[FIRST ? 1 : W][FIRST ? 1 : 64 * (NCH + 1)];
     __shared__ uint32_t q_out, q_shd, q_dead, q_done;
     __shared__ uint32_t tab_lds[TABS ? WF_TAB_DW : 1];
     const uint32_t r = a.region0 + xcd_swizzle(blockIdx.x, gridDim.x), base = r * WF_REGION;
@@ -641,21 +651,23 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
                 const uint32_t hid = hidv[j];
                 const float4 q3 = q3v[j], q4 = q4v[j], q5 = q5v[j];
                 const bool is_hit = hid != 0xffffffffu;
+                float4 Lv = q3;
+                if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
+                    Lv.x = fma_(q4.x, q5.x, Lv.x);
+                    Lv.y = fma_(q4.y, q5.y, Lv.y);
+                    Lv.z = fma_(q4.z, q5.z, Lv.z);
+                }
                 if (valid && !is_hit) {
-                    float4 Lv = q3;
-                    if (!FIRST && q4.w != 0.0f) {  // its shadow ray of the previous bounce got through
-                        Lv.x = fma_(q4.x, q5.x, Lv.x);
-                        Lv.y = fma_(q4.y, q5.y, Lv.y);
-                        Lv.z = fma_(q4.z, q5.z, Lv.z);
-                    }
-                    Lv.w = 0.0f;
-                    Lh[FIRST ? base + s : __float_as_uint(q3.w)] = Lv;
+                    float4 rec = Lv;
+                    rec.w = 0.0f;
+                    Lh[FIRST ? base + s : __float_as_uint(q3.w)] = rec;
                 }
                 const unsigned long long bh = __ballot(is_hit);
                 if (is_hit) {
                     const uint32_t e = list_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bh, 0u));
                     wlist[wid][e] = s;
                     wprim[wid][e] = hid;
+                    if (!FIRST) wlh[wid][e] = Lv;  // (L with the pending contribution, home in .w)
                 }
                 list_n += (uint32_t)__popcll(bh);
             }
@@ -699,15 +711,15 @@ __global__ __launch_bounds__(WF_SHADE_THREADS, WF_SHADE_WAVES_PER_EU) void k_sha
             } else {
                 const float4 *stp = a.st_in + (base + s);
                 const size_t cp = a.cap;
-                const float4 q0 = stp[0], q1 = stp[cp], q2 = stp[2u * cp], q3 = stp[3u * cp], q4 = stp[4u * cp], q5 = stp[5u * cp];
+                const float4 q0 = stp[0], q1 = stp[cp], q2 = stp[2u * cp];
+                const float4 lh = wlh[FIRST ? 0 : wid][FIRST ? 0 : list_n + lane];  // L (pending shadow contribution included), home
                 o = {q0.x, q0.y, q0.z};
                 d = {q1.x, q1.y, q1.z};
                 thr = {q2.x, q2.y, q2.z};
-                L = {q3.x, q3.y, q3.z};
-                if (q4.w != 0.0f) L = {fma_(q4.x, q5.x, L.x), fma_(q4.y, q5.y, L.y), fma_(q4.z, q5.z, L.z)};
+                L = {lh.x, lh.y, lh.z};
                 eta = (a.key_mode == 1 && a.depth == 0) ? 1.0f : q0.w;  // caller rays carry tmax in the eta slot
                 prev_pdf = q1.w;
-                home = __float_as_uint(q3.w);
+                home = __float_as_uint(lh.w);
                 uint32_t px, py;
                 const RadArgs ra = wf_key_args(a);
                 path_key<true>(ra, home, &ka, &kb, &px, &py);

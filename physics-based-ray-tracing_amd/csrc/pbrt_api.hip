@@ -54,12 +54,31 @@ struct pbrt_ctx {
         ws.erase(it);
     }
     std::vector<hipEvent_t> ev_pool;
+    // An acquisition that was queued without waiting (pbrt_us_acquire_queue_dev, ABI 5): what us_finish needs to turn the counters
+    // the device leaves in the pinned page into pbrt_stats once the stream has drained.  Every entry point that waits for the
+    // stream or starts other work on the context finishes it first (ctx_settle).
+    struct PendingAcq {
+        bool active = false, streams = false, tab0 = false;
+        size_t n_ev = 0;
+        uint32_t passes = 0, launches = 0;
+        uint64_t samples = 0, nchan = 0;
+    } pend;
+    // one page of pinned host memory: the statistics and guard words of a call are copied here (a copy to pageable memory blocks
+    // the host until it is done; to pinned memory it is queued like a kernel)
+    void *pinned = nullptr;
+    unsigned long long *pin_stats() { return (unsigned long long *)pinned; }              // [2 + 2 * MAX_DEPTH_STATS]
+    uint32_t *pin_guard() { return (uint32_t *)((char *)pinned + 1024); }                  // [WF_GUARD_WORDS]
+    // the small tables of the last acquisition (transmit delays, primary directions, element positions) as uploaded: the
+    // reference's loop calls the acquisition 51 times with the same ones (USMain.py:260,279-283), three host-to-device copies each
+    std::vector<float> us_tab_host;
+    const void *us_tab_dev = nullptr;
     // image formation (f-1): event pairs per step when profiling is on (pbrt_ctx_set_profiling), read by pbrt_get_image_stats
     bool profiling = false;
     hipEvent_t img_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     uint32_t img_mask = 0;
     uint64_t img_das_bytes = 0;
     size_t env_lds_attr = 0;
+    uint32_t env_taps_n = 0;  // column length the context's tap table (workspace "env_taps") was made for
     bool img_event(int i) { return img_ev[i] || hipEventCreate(&img_ev[i]) == hipSuccess; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t lds_limit = 0;
@@ -146,6 +165,11 @@ struct pbrt_scene {
     do {                                                                       \
         if (!(cond)) return (ctx)->fail(PBRT_E_INVALID, "invalid argument: %s", #cond); \
     } while (0)
+
+// finishes an acquisition that was queued without waiting (pbrt_us_acquire_queue_dev): waits for the stream, checks the guard words,
+// fills pbrt_stats.  Called first by every entry point that waits for the stream or starts other work on the context.
+static int us_finish(pbrt_ctx *c);
+static inline int ctx_settle(pbrt_ctx *c) { return c->pend.active ? us_finish(c) : PBRT_OK; }
 
 template <typename T>
 static int upload(pbrt_scene *s, const T *src, size_t n, const T **dst) {
@@ -297,6 +321,13 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
         delete c;
         return PBRT_E_DEVICE;
     }
+    if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) {
+        g_ctxless_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return PBRT_E_NOMEM;
+    }
+    std::memset(c->pinned, 0, 4096);
     if (const char *lim = getenv("PBRT_WORKSPACE_LIMIT_BYTES")) c->ws_limit = (size_t)strtoull(lim, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -310,11 +341,13 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
 int pbrt_ctx_destroy(pbrt_ctx *c) {
     if (!c) return PBRT_OK;
     (void)hipSetDevice(c->device);
+    (void)ctx_settle(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->st_trace) (void)hipStreamSynchronize(c->st_trace);
     if (c->st_shade) (void)hipStreamSynchronize(c->st_shade);
     for (auto &kv : c->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -332,6 +365,7 @@ const char *pbrt_last_error(pbrt_ctx *c) { return c ? c->err.c_str() : g_ctxless
 
 int pbrt_ctx_set_workspace_limit(pbrt_ctx *c, uint64_t bytes) {
     if (!c) return PBRT_E_INVALID;
+    if (int rc = ctx_settle(c)) return rc;
     c->ws_limit = (size_t)bytes;
     if (bytes && c->ws_total() > bytes) {  // a limit below what the context holds: everything goes back (calls are synchronous, nothing is in use)
         HIPCHK(c, hipSetDevice(c->device));
@@ -347,6 +381,7 @@ int pbrt_ctx_set_workspace_limit(pbrt_ctx *c, uint64_t bytes) {
 // frees every workspace buffer the most recent call did not use, and every one that is larger than that call needed
 int pbrt_ctx_trim(pbrt_ctx *c, uint64_t *held_after) {
     if (!c) return PBRT_E_INVALID;
+    if (int rc = ctx_settle(c)) return rc;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (auto it = c->ws.begin(); it != c->ws.end();) {
@@ -366,6 +401,7 @@ int pbrt_ctx_trim(pbrt_ctx *c, uint64_t *held_after) {
 
 int pbrt_get_stats(pbrt_ctx *c, pbrt_stats *out) {
     if (!c || !out) return PBRT_E_INVALID;
+    if (int rc = ctx_settle(c)) return rc;  // (a queued acquisition: its counters arrive now)
     *out = c->stats;
     return PBRT_OK;
 }
@@ -501,13 +537,17 @@ int pbrt_scene_update_material(pbrt_scene *s, uint32_t index, const pbrt_materia
     pbrt_ctx *c = s->ctx;
     NEED(c, m && index < s->n_mats);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipMemcpy(s->d_mats + index, m, sizeof *m, hipMemcpyHostToDevice));
+    // in the order of the context's stream: behind an acquisition that is still queued, ahead of the next one (the 32 bytes are
+    // staged before the call returns)
+    HIPCHK(c, hipMemcpyAsync(s->d_mats + index, m, sizeof *m, hipMemcpyHostToDevice, c->stream));
     return PBRT_OK;
 }
 
 int pbrt_scene_destroy(pbrt_scene *s) {
     if (!s) return PBRT_OK;
     (void)hipSetDevice(s->ctx->device);
+    (void)ctx_settle(s->ctx);
+    (void)hipStreamSynchronize(s->ctx->stream);  // queued work may still read the scene
     for (void *p : s->allocs) (void)hipFree(p);
     delete s;
     return PBRT_OK;
@@ -981,8 +1021,9 @@ static int wf_check_guard(pbrt_ctx *c, const uint32_t *g) {
     {
         unsigned long long pr[8];
         std::memcpy(pr, g + 32, sizeof pr);
-        fprintf(stderr, "WF_PROBE walk trips %llu lanes %llu (%.3f) | leaf trips %llu lanes %llu (%.3f) | main trips %llu rays %llu busy lanes per trip %.1f\n",
-                pr[0], pr[1], pr[0] ? pr[1] / (64.0 * pr[0]) : 0.0, pr[2], pr[3], pr[2] ? pr[3] / (64.0 * pr[2]) : 0.0, pr[4], pr[5],
+        fprintf(stderr, "WF_PROBE walk trips %llu lanes %llu (%.3f) holding a leaf %.3f idle %.3f | leaf trips %llu lanes %llu (%.3f) | main trips %llu rays %llu busy lanes per trip %.1f\n",
+                pr[0], pr[1], pr[0] ? pr[1] / (64.0 * pr[0]) : 0.0, pr[0] ? pr[7] / (64.0 * pr[0]) : 0.0,
+                pr[0] ? 1.0 - (pr[1] + pr[7]) / (64.0 * pr[0]) : 0.0, pr[2], pr[3], pr[2] ? pr[3] / (64.0 * pr[2]) : 0.0, pr[4], pr[5],
                 pr[4] ? (double)pr[6] / pr[4] : 0.0);
         (void)hipMemsetAsync(wf_guard(c) + 32, 0, 64, c->stream);
     }
@@ -1033,6 +1074,7 @@ static uint64_t wavefront_model_bytes(const unsigned long long *live, const unsi
 
 static int render_impl(pbrt_scene *s, const pbrt_camera *cam, const pbrt_film_desc *f, void *d_out) {
     pbrt_ctx *c = s->ctx;
+    if (int rcs = ctx_settle(c)) return rcs;
     NEED(c, cam && f && d_out);
     const uint32_t W = cam->film_w, H = cam->film_h;
     NEED(c, W > 0 && H > 0 && f->crop_w > 0 && f->crop_h > 0);
@@ -1498,6 +1540,7 @@ int pbrt_integrator_sample(pbrt_scene *s, uint32_t n, const float *o, const floa
     NEED(c, o && d && tmax && rgb && max_depth > 0);
     if (n == 0) return PBRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
+    if (int rcs = ctx_settle(c)) return rcs;
     int rc = set_lds_attr(s);
     if (rc) return rc;
     ++c->call_seq;
@@ -1796,8 +1839,9 @@ static int us_wf_pass(pbrt_scene *s, UsArgs a, const WfBufs &b, const WfPlan &p,
 extern "C" {
 
 static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
-                   uint32_t norm_paths, float *d_channel, float *tx_host) {
+                   uint32_t norm_paths, float *d_channel, float *tx_host, bool wait = true) {
     pbrt_ctx *c = s->ctx;
+    if (int rcs = ctx_settle(c)) return rcs;
     NEED(c, p && d_channel);
     NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
     NEED(c, (uint64_t)p->n_angles * p->n_elements * p->time_samples < 0xffffffffull);  // channel index is 32-bit (echo bins)
@@ -1898,26 +1942,36 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
         segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     }
-    unsigned long long *dstats = (unsigned long long *)c->buf("stats", (2 + MAX_DEPTH_STATS) * 8);
+    // the totals (a 512-byte head) and the rows they are reduced from in ONE buffer: one fill command clears both
     const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
-    unsigned long long *segstats = (unsigned long long *)c->buf("segstats", segstats_bytes);
-    if (!segstats) return PBRT_E_NOMEM;
+    static_assert((2 + MAX_DEPTH_STATS) * 8 <= 512, "the totals fit the head of the statistics buffer");
+    unsigned long long *dstats = (unsigned long long *)c->buf("us_stats", 512 + segstats_bytes);
+    if (!dstats) return PBRT_E_NOMEM;
+    unsigned long long *segstats = dstats + 64;
     float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
     const char *e_fused = getenv("PBRT_US_EMIT_FUSED");  // A/B: draw the emitter ray inside the first-bounce kernel
     const bool emit_fused = e_fused && atoi(e_fused) != 0;
-    if (emit)  // the ray's own emission time rides in its time of flight (CustomEmmitter.py:93-94); t0 of :329 is 0
-        HIPCHK(c, hipMemsetAsync(d_tx, 0, (size_t)n_rays * 4, st));
-    else
-        HIPCHK(c, hipMemcpyAsync(d_tx, tx.data(), (size_t)n_rays * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_dir, dir0.data(), (size_t)NA * 12, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_ex, ex.data(), (size_t)NE * 4, hipMemcpyHostToDevice, st));
+    // the three small tables in one host image; uploaded only when they differ from what the device copy already holds
+    {
+        std::vector<float> img((size_t)n_rays + 3 * NA + NE);
+        if (emit)  // the ray's own emission time rides in its time of flight (CustomEmmitter.py:93-94); t0 of :329 is 0
+            std::fill(img.begin(), img.begin() + n_rays, 0.0f);
+        else
+            std::copy(tx.begin(), tx.end(), img.begin());
+        std::copy(dir0.begin(), dir0.end(), img.begin() + n_rays);
+        std::copy(ex.begin(), ex.end(), img.begin() + n_rays + 3 * NA);
+        if (c->us_tab_dev != (const void *)tabs || c->us_tab_host != img) {
+            HIPCHK(c, hipMemcpyAsync(tabs, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
+            c->us_tab_host.swap(img);
+            c->us_tab_dev = tabs;
+        }
+    }
     const size_t nchan = (size_t)n_rays * T;
     HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
-    HIPCHK(c, hipMemsetAsync(dstats, 0, (2 + MAX_DEPTH_STATS) * 8, st));
-    HIPCHK(c, hipMemsetAsync(segstats, 0, segstats_bytes, st));
+    HIPCHK(c, hipMemsetAsync(dstats, 0, 512 + segstats_bytes, st));
     HIPCHK(c, hipEventRecord(c->ev0, st));
     UsArgs a{};
     a.sc = s->ds;
@@ -2024,31 +2078,51 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->ev1, st));
-    unsigned long long hstats[2 + MAX_DEPTH_STATS];
     hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(hstats, dstats, sizeof hstats, hipMemcpyDeviceToHost, st));
-    uint32_t hguard[WF_GUARD_WORDS] = {0};
-    if (streams && (rc = wf_guard_fetch(c, hguard)) != 0) return rc;
+    // counters and guard words into the context's pinned page (queued copies), read by us_finish once the stream has drained
+    HIPCHK(c, hipMemcpyAsync(c->pin_stats(), dstats, (2 + MAX_DEPTH_STATS) * 8, hipMemcpyDeviceToHost, st));
+    if (streams && (rc = wf_guard_fetch(c, c->pin_guard())) != 0) return rc;
+    pbrt_ctx::PendingAcq &P = c->pend;
+    P.active = true;
+    P.streams = streams;
+    P.tab0 = a.first_hit != nullptr;
+    P.n_ev = n_ev;
+    P.passes = passes;
+    P.launches = launches;
+    P.samples = (uint64_t)n_rays * ppr;
+    P.nchan = nchan;
+    return wait ? us_finish(c) : PBRT_OK;
+}
+
+}  // extern "C"
+
+static int us_finish(pbrt_ctx *c) {
+    pbrt_ctx::PendingAcq P = c->pend;
+    c->pend.active = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->stream;
     HIPCHK(c, hipStreamSynchronize(st));
-    if (streams && (rc = wf_check_guard(c, hguard)) != 0) return rc;
+    int rc;
+    if (P.streams && (rc = wf_check_guard(c, c->pin_guard())) != 0) return rc;
+    const unsigned long long *hstats = c->pin_stats();
     float ms = 0.0f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;
-    for (size_t i = 0; i + 1 < n_ev; i += 2) {
+    for (size_t i = 0; i + 1 < P.n_ev; i += 2) {
         float t = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1]));
         bounce_ms += t;
     }
     pbrt_stats &S = c->stats;
     S = pbrt_stats{};
-    S.samples = (uint64_t)n_rays * ppr;
+    S.samples = P.samples;
     S.segments = hstats[0];
     S.shadow_rays = hstats[1];
     S.kernel_ms = ms;
     S.bounce_ms = bounce_ms;
-    S.bounce_launches = launches;
-    S.passes = passes;
+    S.bounce_launches = P.launches;
+    S.passes = P.passes;
     for (int d = 0; d < 16; ++d) S.live[d] = hstats[2 + d];
     uint64_t bb = 0;
     for (uint32_t d = 0; d < MAX_DEPTH_STATS; ++d) {
@@ -2057,12 +2131,12 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         bb += next * (N_USTATE * 4);
     }
     bb += hstats[0] * 8;  // one f32 atomic (read-modify-write) per shaded segment, upper bound
-    if (streams) {
+    if (P.streams) {
         // k_trace + k_us_shade (kernels_us_wavefront.h), the bytes the algorithm needs: per ray that is traced 32 B read + 4 B hit
         // index written and read back; a path's pending echo (32 B) is read once,
         // the rest of its state (32 B) if it hit; 64 B per survivor; an occlusion ray is 32 B written, 32 B read, 4 B answered.
         // (With the first-bounce tables depth 0 traces and reads nothing.)  Occlusion rays: one per shaded segment at most.
-        const bool tab0 = a.first_hit != nullptr;
+        const bool tab0 = P.tab0;
         uint64_t tr = 0, sh = 0;
         for (uint32_t d = 0; d < MAX_DEPTH_STATS; ++d) {
             const uint64_t in = hstats[2 + d], next = d + 1 < MAX_DEPTH_STATS ? hstats[2 + d + 1] : 0;
@@ -2080,15 +2154,25 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         S.trace_model_bytes = tr;
     }
     S.bounce_model_bytes = bb;
-    S.model_bytes = bb + nchan * 12;  // clear + scale pass over the channel buffer
+    S.model_bytes = bb + P.nchan * 12;  // clear + scale pass over the channel buffer
+    S.workspace_bytes = c->ws_total();
     return PBRT_OK;
 }
+
+extern "C" {
 
 int pbrt_us_acquire_dev(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
                         uint32_t norm_paths, void *d_channel, float *tx) {
     if (!s) return PBRT_E_INVALID;
     ++s->ctx->call_seq;
     return us_impl(s, p, seed, ppr, path_offset, norm_paths, (float *)d_channel, tx);
+}
+
+int pbrt_us_acquire_queue_dev(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
+                              uint32_t norm_paths, void *d_channel, float *tx) {
+    if (!s) return PBRT_E_INVALID;
+    ++s->ctx->call_seq;
+    return us_impl(s, p, seed, ppr, path_offset, norm_paths, (float *)d_channel, tx, false);
 }
 
 int pbrt_us_acquire(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
@@ -2365,24 +2449,32 @@ static int das_enqueue(pbrt_ctx *c, const pbrt_das_params *p, const float *dd, c
     return PBRT_OK;
 }
 static int env_enqueue(pbrt_ctx *c, uint32_t nx, uint32_t nz, const float *din, float *dout) {
+    const uint32_t np = (nz + 3u) & ~3u, G = 2u * np + 8u;
+    // the tap table of this column length: made once, kept while the workspace buffer lives (pbrt_ctx_trim may take it)
+    const bool fresh = c->ws.find("env_taps") == c->ws.end() || c->ws["env_taps"].p == nullptr;
+    float *taps = (float *)c->buf("env_taps", (size_t)(2u * ENV_MAX_N + 8u) * 4);
+    if (!taps) return PBRT_E_NOMEM;
     ImgTimer tm(c, IMG_ENV);
-    const uint32_t np = (nz + 3u) & ~3u;
+    if (fresh || c->env_taps_n != nz) {
+        hipLaunchKernelGGL(k_hilbert_taps, dim3(div_up(G, 256)), dim3(256), 0, c->stream, nz, taps);
+        c->env_taps_n = nz;
+    }
     const size_t lds = (size_t)(3u * np + 8u) * 4;
     if (lds > c->env_lds_attr) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->env_lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), dim3(256), lds, c->stream, nz, din, dout);
+    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), dim3(256), lds, c->stream, nz, din, taps, dout);
     HIPCHK(c, hipGetLastError());
     return PBRT_OK;
 }
 static int log_enqueue(pbrt_ctx *c, uint32_t n, const float *din, float dr, float *dout) {
-    uint32_t *mx = (uint32_t *)c->buf("img_max", 256);
+    float *mx = (float *)c->buf("img_max", ENV_MAX_BLOCKS * 4);
     if (!mx) return PBRT_E_NOMEM;
     ImgTimer tm(c, IMG_LOG);
-    HIPCHK(c, hipMemsetAsync(mx, 0, 4, c->stream));
-    hipLaunchKernelGGL(k_env_max, dim3(std::min<uint32_t>(div_up(n, 256), 1024)), dim3(256), 0, c->stream, n, din, mx);
-    hipLaunchKernelGGL(k_log_compress, dim3(div_up(n, 256)), dim3(256), 0, c->stream, n, din, mx, dr, dout);
+    const uint32_t nb = std::max(1u, std::min<uint32_t>(div_up(n, 1024), ENV_MAX_BLOCKS));
+    hipLaunchKernelGGL(k_env_max, dim3(nb), dim3(256), 0, c->stream, n, din, mx);
+    hipLaunchKernelGGL(k_log_compress, dim3(div_up(n, 256)), dim3(256), 0, c->stream, n, din, mx, nb, dr, dout);
     HIPCHK(c, hipGetLastError());
     return PBRT_OK;
 }
@@ -2516,7 +2608,7 @@ int pbrt_ctx_synchronize(pbrt_ctx *c) {
     if (!c) return PBRT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PBRT_OK;
+    return ctx_settle(c);  // (a queued acquisition: its guard words are looked at now)
 }
 
 int pbrt_ctx_set_profiling(pbrt_ctx *c, int on) {
@@ -2562,6 +2654,7 @@ int pbrt_dev_free(pbrt_ctx *c, void *p) {
     if (!p) return PBRT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // queued work may still read or write it
+    (void)ctx_settle(c);
     HIPCHK(c, hipFree(p));
     return PBRT_OK;
 }
@@ -2582,7 +2675,7 @@ int pbrt_dev_download(pbrt_ctx *c, void *dst_host, const void *src_dev, uint64_t
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes) HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return PBRT_OK;
+    return ctx_settle(c);  // an acquisition queued ahead of this copy that tripped its guard makes the copy's content invalid
 }
 
 }  // extern "C"

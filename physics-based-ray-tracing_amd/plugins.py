@@ -725,6 +725,18 @@ class UltraIntegrator(SamplingIntegrator):
         if self.primary_rays not in ("element", "emitter"):
             raise ValueError("primary_rays must be 'element' or 'emitter'")
 
+    # ray_count (CustomIntegrator.py:231,360,402): segments traced by the last acquisition; after a queued acquisition the counter
+    # is fetched when somebody reads it (that waits for the stream)
+    @property
+    def ray_count(self):
+        if self._ray_count is None and getattr(self, "_stats_ctx", None) is not None:
+            self._ray_count = int(self._stats_ctx.stats()["segments"])
+        return self._ray_count or 0
+
+    @ray_count.setter
+    def ray_count(self, value):
+        self._ray_count = int(value)
+
     # channel_buf (CustomIntegrator.py:43,260; read at USMain.py:103): a host array, as in the reference.  When an acquisition
     # left its result in HBM (us_render keeps the whole loop on the device) the copy to the host happens on first read.
     @property
@@ -780,7 +792,8 @@ class UltraIntegrator(SamplingIntegrator):
             p.emitter = ems[0]._desc()
         return p
 
-    def _acquire(self, scene, quirks, paths_per_ray=None, path_offset=0, norm_paths=None, seed=None, out_dev=None, pulse=None):
+    def _acquire(self, scene, quirks, paths_per_ray=None, path_offset=0, norm_paths=None, seed=None, out_dev=None, pulse=None,
+                 queue=False):
         """pulse: apply the Gaussian-windowed carrier when the echoes were deposited without one (pulse_model
         'gaussian' = PBRT_USQ_NO_CARRIER).  Default: yes for a host buffer.  A device buffer (out_dev) is one shard of a
         sum that is still to be reduced, so the caller convolves the REDUCED buffer once (parallel.distributed_acquire
@@ -796,15 +809,19 @@ class UltraIntegrator(SamplingIntegrator):
             raise ValueError("pulse_model 'gaussian' with a device output buffer: the pulse is applied to the reduced buffer "
                              "(parallel.distributed_acquire); pass pulse=False to get this shard's bare echo amplitudes")
         if out_dev is not None:
-            dev.ctx.check(dev.ctx.lib.pbrt_us_acquire_dev(dev.handle, C.byref(p), sd, ppr, int(path_offset), norm,
-                                                           C.c_void_p(int(out_dev)), _capi.addr(tx)), "pbrt_us_acquire_dev")
+            # queue=True: pbrt_us_acquire_queue_dev -- the call returns with the acquisition queued on the context's stream; its
+            # statistics (ray_count) arrive with the next call that waits
+            fn = dev.ctx.lib.pbrt_us_acquire_queue_dev if queue else dev.ctx.lib.pbrt_us_acquire_dev
+            dev.ctx.check(fn(dev.handle, C.byref(p), sd, ppr, int(path_offset), norm, C.c_void_p(int(out_dev)), _capi.addr(tx)),
+                          "pbrt_us_acquire_queue_dev" if queue else "pbrt_us_acquire_dev")
             buf = None
         else:
             buf = np.empty((self.n_angles, self.n_elements, self.time_samples), np.float32)
             dev.ctx.check(dev.ctx.lib.pbrt_us_acquire(dev.handle, C.byref(p), sd, ppr, int(path_offset), norm,
                                                        _capi.addr(buf), _capi.addr(tx)), "pbrt_us_acquire")
         self.transmission_delays_buf = tx
-        self.ray_count = int(dev.ctx.stats()["segments"])
+        self._ray_count = None if queue else int(dev.ctx.stats()["segments"])
+        self._stats_ctx = dev.ctx
         if buf is not None and no_carrier and pulse is not False:
             # f-3 pulse model: the echoes were deposited as plain amplitudes; give every trace the Gaussian-windowed carrier
             from .beamform import apply_pulse

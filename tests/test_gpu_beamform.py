@@ -238,3 +238,32 @@ def test_envelope_of_odd_and_even_columns_against_scipy_definition(mi):
         ref = obf.envelope(rf)
         got = mi.envelope(rf)
         assert np.allclose(got, ref, rtol=0, atol=2e-4 * max(ref.max(), 1e-6)), N
+
+
+def test_a_queued_acquisition_reports_with_the_next_waiting_call(mi, capi):
+    """pbrt_us_acquire_queue_dev (ABI 5): the call returns with the acquisition queued; the channel buffer is complete for the kernels
+    queued behind it and for the host after a download; statistics (and a tripped guard) arrive with the next call that waits."""
+    sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=64, seed=9)
+    ui = sc.integrator()
+    cx = sc.device().ctx
+    ref = ui._acquire(sc, ui.quirks)                                                      # host buffer, synchronous
+    seg_ref = cx.stats()["segments"]
+    d = mi.DeviceBuffer(cx, (ui.n_angles, ui.n_elements, ui.time_samples))
+    ui._acquire(sc, ui.quirks, out_dev=d.ptr, queue=True)
+    assert ui._ray_count is None                                                          # nothing has waited yet
+    got = d.numpy()                                                                       # waits, finishes the queued call
+    assert np.array_equal(got != 0, ref != 0) and np.allclose(got, ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())
+    assert ui.ray_count == seg_ref == cx.stats()["segments"] and cx.stats()["samples"] == 5 * 64 * 64
+    # two queued acquisitions back to back into two buffers, a material update between them (in stream order), one wait at the end
+    d2 = mi.DeviceBuffer(cx, d.shape)
+    params = mi.traverse(sc)
+    key = [k for k in params.keys() if k.endswith("flat_plate.bsdf.roughness")][0]
+    ui._acquire(sc, ui.quirks, out_dev=d.ptr, queue=True)
+    params[key] = 0.3
+    params.update()
+    ui._acquire(sc, ui.quirks, out_dev=d2.ptr, queue=True)
+    a, b = d.numpy(), d2.numpy()
+    assert np.allclose(a, ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max()) and not np.allclose(b, ref, rtol=1e-3, atol=1e-6 * np.abs(ref).max())
+    params[key] = 0.7
+    params.update()
+    assert np.allclose(ui._acquire(sc, ui.quirks), ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())

@@ -326,8 +326,19 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
     def step():
         t_a = time.perf_counter()
         if radiance:
-            tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
-                                            tile=keep.get("tile"), pass_paths=cfg.get("pass_paths", 0) if world == 1 else 0)
+            try:
+                tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
+                                                tile=keep.get("tile"), pass_paths=cfg.get("pass_paths", 0) if world == 1 else 0)
+            except RuntimeError as e:
+                # the one-pass size of config 4 needs 183 GB: on a device that cannot give them, go on with the library's default
+                # (and say so in the record)
+                if not (world == 1 and cfg.get("pass_paths")):
+                    raise
+                cfg["pass_paths"] = 0
+                cfg["what"] += f" [pass_paths request refused: {str(e)[:80]}; library default used]"
+                ctx.trim()
+                tile, layout = par.render_tiles(scene, SPP, seed, rank, world, band_rows, device=device, on_call=account,
+                                                tile=keep.get("tile"))
             keep["tile"] = tile
             if args.rehearse_on_one_gpu and world > 1:
                 tile = tile.cpu()  # gloo gathers host tensors
@@ -349,13 +360,6 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         mine["coll"] += tm.get("collective_s", 0.0)
         return buf
 
-    if radiance and world == 1 and cfg.get("pass_paths"):
-        try:  # the one-pass size needs 183 GB: on a device that cannot give them, fall back to the library's default (and say so)
-            step()
-        except RuntimeError as e:
-            cfg["pass_paths"] = 0
-            cfg["what"] += f" [pass_paths request refused: {str(e)[:80]}; library default used]"
-            ctx.trim()
     for _ in range(warmup):
         step()
     if warmup == 0 and radiance and (world > 1 or env["force"]):  # no warm-up step to allocate the gather list in

@@ -289,10 +289,15 @@ DEV bool brute_intersect(const DevScene &sc, V3 o, V3 d, float tmax, Hit *h) {
     if (n_list == 0) return false;
     // software pipeline over the (wave-uniform) primitive records: the 64-byte scalar load of primitive
     // i + 1 is in flight while primitive i is tested
+#ifdef PBRT_BRUTE_NO_PREFETCH  // A/B (round 5): one record in scalar registers instead of two (16 SGPRs for kernels that spill them)
+    for (uint32_t i = 0; i < n_list; ++i) {
+        const pbrt_prim P = load_prim_uniform(list + i);
+#else
     pbrt_prim nxt = load_prim_uniform(list);
     for (uint32_t i = 0; i < n_list; ++i) {
         const pbrt_prim P = nxt;
         nxt = load_prim_uniform(list + min(i + 1, n_list - 1));
+#endif
         const uint32_t type = P.type;  // wave-uniform
         bool ok;
         float num, den, us, vs;

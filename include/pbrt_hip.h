@@ -502,6 +502,15 @@ int pbrt_us_acquire_queue_dev(pbrt_scene *scene, const pbrt_us_params *p, uint32
  * d_x [nx], d_z [nz], d_out [nx][nz]. */
 int pbrt_das_beamform_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_data, const void *d_tx_delays,
                           const void *d_elem_x, const void *d_x, const void *d_z, void *d_out);
+/* The transmit half of the delays depends on the transmit delays and the scan grid only, and the reference's loop changes neither
+ * (one probe, one GridScan, 51 renders: USMain.py:129-204): pbrt_das_first_arrival_dev writes the table
+ *     d_table[a][ix][iz] (double) = t_tx(a; x, z) = min_e' (tx_delays[a][e'] + |(x, z) - (elem_x[e'], 0)| / c)
+ * once, pbrt_das_beamform_table_dev beamforms with it: the same image bit for bit as pbrt_das_beamform_dev (which evaluates that
+ * minimum per call), without the pass over all elements.  Both queue their kernel on the context's stream and return. */
+int pbrt_das_first_arrival_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_tx_delays, const void *d_elem_x,
+                               const void *d_x, const void *d_z, void *d_table);
+int pbrt_das_beamform_table_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_data, const void *d_table,
+                                const void *d_elem_x, const void *d_x, const void *d_z, void *d_out);
 /* replaces: DelayAndSum.compute_envelope (USMain.py:205); d_rf, d_env [nx][nz], distinct buffers */
 int pbrt_envelope_dev(pbrt_ctx *ctx, uint32_t nx, uint32_t nz, const void *d_rf, void *d_env);
 /* replaces: the log compression of USMain.py:210-218; d_env, d_out [n] (may be the same buffer) */

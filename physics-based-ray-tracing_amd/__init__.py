@@ -27,7 +27,7 @@ from .scene import (Film, Object, ParamFlags, ReconstructionFilter, Sampler, Sce
                     load_file, register_bsdf, register_emitter, register_film, register_integrator, register_rfilter,
                     register_sampler, register_sensor, register_shape, traverse)
 from .transforms import Properties, ScalarTransform4f, Transform4f
-from .beamform import (DelayAndSum, GridScan, apply_pulse, build_probe, das_beamform, envelope, log_compress,
+from .beamform import (DelayAndSum, GridScan, apply_pulse, build_probe, das_beamform, das_first_arrival, envelope, log_compress,
                        us_render)
 
 # NB: the receive-side accumulator class `CustomSensor` is reached as pbrt_amd.CustomSensor.CustomSensor (module of

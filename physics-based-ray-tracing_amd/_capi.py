@@ -192,6 +192,8 @@ SIGNATURES = {
     "pbrt_us_apply_pulse": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _F, _F]),
     # ABI 5: image formation on device pointers (queued on the ctx stream, no synchronisation), device buffers, the stream
     "pbrt_das_beamform_dev": (C.c_int, [_P, C.POINTER(DasParams), _P, _P, _P, _P, _P, _P]),
+    "pbrt_das_first_arrival_dev": (C.c_int, [_P, C.POINTER(DasParams), _P, _P, _P, _P, _P]),
+    "pbrt_das_beamform_table_dev": (C.c_int, [_P, C.POINTER(DasParams), _P, _P, _P, _P, _P, _P]),
     "pbrt_envelope_dev": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "pbrt_log_compress_dev": (C.c_int, [_P, C.c_uint32, _P, C.c_float, _P]),
     "pbrt_us_apply_pulse_dev": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float, _P, _P]),

@@ -40,13 +40,34 @@ def _to_dev(cx, a, shape=None) -> "_capi.DeviceBuffer":
     return _capi.DeviceBuffer.from_host(cx, a if shape is None else a.reshape(shape))
 
 
+def das_first_arrival(tx_delays, elem_x, x, z, sound_speed, out=None):
+    """first-arrival table of a scan, [n_angles, nx, nz] float64 in HBM: t_tx(a; x, z) = min_e (tx_delays[a, e] + distance to element e / c)
+    (pbrt_das_first_arrival_dev).  It depends on the delays and the grid only: a loop that changes neither (USMain.py:262-289) makes it
+    once and hands it to every das_beamform(..., table=...) call, which then skips its pass over all elements (same image bit for bit)."""
+    cx = next((a.ctx for a in (tx_delays, elem_x, x, z) if _is_dev(a)), None) or _capi.default_context()
+    d_tx = tx_delays if _is_dev(tx_delays) else _to_dev(cx, np.atleast_2d(np.asarray(tx_delays)))
+    A, E = d_tx.shape
+    d_ex = _to_dev(cx, elem_x, (E,))
+    d_x = x if _is_dev(x) else _to_dev(cx, np.asarray(x).ravel())
+    d_z = z if _is_dev(z) else _to_dev(cx, np.asarray(z).ravel())
+    nx, nz = d_x.shape[0], d_z.shape[0]
+    p = _das_params(A, E, 2, nx, nz, 1.0, sound_speed, 0.0, 0.0, "linear", "sum")
+    tab = out if out is not None else _capi.DeviceBuffer(cx, (A, nx, nz), np.float64)
+    if tab.nbytes != A * nx * nz * 8:
+        raise ValueError("out must hold n_angles * nx * nz float64")
+    cx.check(cx.lib.pbrt_das_first_arrival_dev(cx.handle, C.byref(p), d_tx.ptr, d_ex.ptr, d_x.ptr, d_z.ptr, tab.ptr), "pbrt_das_first_arrival_dev")
+    tab._keep = (d_tx, d_ex, d_x, d_z)
+    return tab
+
+
 def das_beamform(data, tx_delays, elem_x, x, z, fs, sound_speed, t0=0.0, f_number=1.0, interpolation="linear",
-                 compound="sum", out=None):
+                 compound="sum", out=None, table=None):
     """data [n_angles, n_elements, T] f32, tx_delays [n_angles, n_elements] (s), elem_x [n_elements] (m),
     grid x [nx], z [nz] (m)  ->  beamformed RF image [nx, nz].
     Host arrays in: pbrt_das_beamform, a host array out.  `data` a DeviceBuffer (the channel buffer of an acquisition that
     stayed in HBM): pbrt_das_beamform_dev -- the small tables are uploaded if they are host arrays, the kernel is queued on
-    the context's stream and the result is a DeviceBuffer (`out`, or a new one); nothing waits."""
+    the context's stream and the result is a DeviceBuffer (`out`, or a new one); nothing waits.  table: the scan's first-arrival
+    times from das_first_arrival (pbrt_das_beamform_table_dev)."""
     cx = data.ctx if _is_dev(data) else _capi.default_context()
     if _is_dev(data):
         if len(data.shape) != 3:
@@ -60,9 +81,15 @@ def das_beamform(data, tx_delays, elem_x, x, z, fs, sound_speed, t0=0.0, f_numbe
         d_out = out if out is not None else _capi.DeviceBuffer(cx, (nx, nz))
         if d_out.nbytes != nx * nz * 4:
             raise ValueError("out must hold nx * nz float32")
-        cx.check(cx.lib.pbrt_das_beamform_dev(cx.handle, C.byref(p), data.ptr, d_tx.ptr, d_ex.ptr, d_x.ptr, d_z.ptr, d_out.ptr),
-                 "pbrt_das_beamform_dev")
-        d_out._keep = (d_tx, d_ex, d_x, d_z)  # the queued kernel reads them: they live as long as its result
+        if table is not None:   # the first-arrival times of this scan, made once (das_first_arrival)
+            if table.nbytes != A * nx * nz * 8:
+                raise ValueError("table must be the [n_angles, nx, nz] float64 buffer of das_first_arrival for this scan")
+            cx.check(cx.lib.pbrt_das_beamform_table_dev(cx.handle, C.byref(p), data.ptr, table.ptr, d_ex.ptr, d_x.ptr, d_z.ptr, d_out.ptr),
+                     "pbrt_das_beamform_table_dev")
+        else:
+            cx.check(cx.lib.pbrt_das_beamform_dev(cx.handle, C.byref(p), data.ptr, d_tx.ptr, d_ex.ptr, d_x.ptr, d_z.ptr, d_out.ptr),
+                     "pbrt_das_beamform_dev")
+        d_out._keep = (d_tx, d_ex, d_x, d_z, table)  # the queued kernel reads them: they live as long as its result
         return d_out
     data = _capi.f32(np.asarray(data))
     if data.ndim != 3:
@@ -178,7 +205,7 @@ class DelayAndSum:
             raise KeyError(name)
         self.setups[name] = value
 
-    def beamform(self, d_data, scan, out=None):
+    def beamform(self, d_data, scan, out=None, table=None):
         """host array in -> host array out; a DeviceBuffer in (the channel buffer left in HBM) -> a DeviceBuffer out, queued"""
         ai = self.acquisition_info
         if ai is None or self.probe is None:
@@ -195,7 +222,7 @@ class DelayAndSum:
         gz = scan.d_z if dev and getattr(scan, "d_z", None) is not None else scan.z_axis
         return das_beamform(data, ai["delays"], ex, gx, gz, ai["sampling_freq"], ai["sound_speed"], t0=ai.get("t0", 0.0) or 0.0,
                             f_number=self.setups["f_number"], interpolation=self.setups["interpolation"],
-                            compound=self.setups["compound"], out=out)
+                            compound=self.setups["compound"], out=out, table=table if dev else None)
 
     def compute_envelope(self, d_output, scan=None, out=None):
         return envelope(d_output, out=out)
@@ -222,6 +249,7 @@ class _RenderPlan:
         self.d_bf = _capi.DeviceBuffer(cx, (nx, nz))
         self.d_env = _capi.DeviceBuffer(cx, (nx, nz))
         self.d_img = _capi.DeviceBuffer(cx, (nx, nz))
+        self.d_table = _capi.DeviceBuffer(cx, (A, nx, nz), np.float64)   # first-arrival times of this scan (das_first_arrival)
 
 
 def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range=60.0, step=None, seed=None,
@@ -279,6 +307,9 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
     if plan.tx_host is None or not np.array_equal(plan.tx_host, delays):
         plan.d_tx.upload(delays)
         plan.tx_host = delays.copy()
+        # the scan's first-arrival times follow the delays and the grid: made again only when those change (never, in the loop
+        # of USMain.py:262-289)
+        das_first_arrival(plan.d_tx, plan.d_ex, plan.d_x, plan.d_z, integ.sound_speed, out=plan.d_table)
     rf = plan.d_channel
     if gaussian:                                                                                       # f-3: carrier on the device
         rf = apply_pulse(plan.d_channel, integ.fs, integ.frequency, integ.pulse_sigma, out=plan.d_rf)
@@ -286,7 +317,7 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
     bf.automatic_setup(info(plan.d_tx), probe)                                                         # :175
     scan.d_x, scan.d_z = plan.d_x, plan.d_z
     bf.probe_dev = plan.d_ex
-    d_bf = bf.beamform(rf, scan, out=plan.d_bf)                                                        # :204
+    d_bf = bf.beamform(rf, scan, out=plan.d_bf, table=plan.d_table)                                    # :204
     d_env = bf.compute_envelope(d_bf, scan, out=plan.d_env)                                            # :205
     d_img = log_compress(d_env, dynamic_range, out=plan.d_img)                                         # :210-218
     t2 = _time.perf_counter()

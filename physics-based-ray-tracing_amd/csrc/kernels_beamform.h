@@ -114,11 +114,43 @@ DEV double das_lane_f64(double v, uint32_t e) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-template <uint32_t INTERP>
+// first-arrival table of a scan: ttx[a][ix][iz] = min_e (tx[a][e] + |(x, z) - (x_e, 0)| / c), the statement of k_das_beamform's first
+// pass (same operands, same operations: the same doubles).  One thread per pixel, z fastest.
+__global__ __launch_bounds__(256) void k_das_first_arrival(pbrt_das_params p, const float *__restrict__ tx, const float *__restrict__ elem_x,
+                                                           const float *__restrict__ gx, const float *__restrict__ gz,
+                                                           double *__restrict__ ttx) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.nx * p.nz) return;
+    const uint32_t ix = idx / p.nz, iz = idx - ix * p.nz;
+    const double x = (double)gx[ix], z = (double)gz[iz], zz = z * z, inv_c = 1.0 / (double)p.sound_speed;
+    const uint32_t A = p.n_angles, E = p.n_elements;
+    const size_t plane = (size_t)p.nx * p.nz;
+    for (uint32_t a0 = 0; a0 < A; a0 += DAS_ANG) {
+        const uint32_t na = min((uint32_t)DAS_ANG, A - a0);
+        double tmin[DAS_ANG];
+#pragma unroll
+        for (uint32_t j = 0; j < DAS_ANG; ++j) tmin[j] = 1e300;
+        for (uint32_t e = 0; e < E; ++e) {
+            const double dx = x - (double)elem_x[e];
+            const double d = das_dist(dx * dx + zz) * inv_c;
+#pragma unroll
+            for (uint32_t j = 0; j < DAS_ANG; ++j)
+                if (j < na) tmin[j] = fmin(tmin[j], (double)tx[(size_t)(a0 + j) * E + e] + d);
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < DAS_ANG; ++j)
+            if (j < na) ttx[(size_t)(a0 + j) * plane + idx] = tmin[j];
+    }
+}
+
+// TABLE: the first-arrival times come from a table [n_angles][nx][nz] of doubles (k_das_first_arrival: the same minimum, made once
+// for a scan whose delays and grid do not change -- the 51 renders of USMain.py share one) instead of a pass over all elements
+// per call; the rest of the kernel, and every bit of its result, is the same.
+template <uint32_t INTERP, bool TABLE>
 __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params p, DasGrid grid, const float *__restrict__ data,
                                                                  const float *__restrict__ tx, const float *__restrict__ elem_x,
                                                                  const float *__restrict__ gx, const float *__restrict__ gz,
-                                                                 float *__restrict__ out) {
+                                                                 const double *__restrict__ ttx, float *__restrict__ out) {
     __shared__ double s_tmin[DAS_SPLIT][DAS_ANG][64];
     __shared__ float s_acc[DAS_SPLIT][64];
     uint32_t tile_x, tile_z;
@@ -155,7 +187,13 @@ __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params
         double tmin[DAS_ANG];
 #pragma unroll
         for (uint32_t j = 0; j < DAS_ANG; ++j) tmin[j] = 1e300;
-        for (uint32_t eb = 0; eb < E; eb += 64u) {
+        if (TABLE) {
+            const size_t pix = (size_t)min(ix, p.nx - 1u) * p.nz + min(iz, p.nz - 1u), plane = (size_t)p.nx * p.nz;
+#pragma unroll
+            for (uint32_t j = 0; j < DAS_ANG; ++j)
+                if (j < na) tmin[j] = ttx[(size_t)(a0 + j) * plane + pix];
+        }
+        for (uint32_t eb = 0; !TABLE && eb < E; eb += 64u) {
             const uint32_t ne = min(64u, E - eb), le = min(lane, ne - 1u);
             const double ex_l = (double)elem_x[eb + le];
             double tx_l[DAS_ANG];
@@ -170,7 +208,7 @@ __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params
             }
         }
         // ... and the minimum over the waves
-        if (DAS_SPLIT > 1) {
+        if (DAS_SPLIT > 1 && !TABLE) {
             if (a0) __syncthreads();  // the previous trip's table has been read
 #pragma unroll
             for (uint32_t j = 0; j < DAS_ANG; ++j)

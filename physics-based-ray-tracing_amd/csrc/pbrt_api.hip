@@ -2424,7 +2424,7 @@ static int das_check(pbrt_ctx *ctx, const pbrt_das_params *p) {
     return PBRT_OK;
 }
 static int das_enqueue(pbrt_ctx *c, const pbrt_das_params *p, const float *dd, const float *dt, const float *de, const float *dx,
-                       const float *dz, float *dout) {
+                       const float *dz, float *dout, const double *ttx = nullptr) {
     ImgTimer tm(c, IMG_DAS);
     DasGrid g;
     g.ntx = div_up(p->nx, DAS_TILE);
@@ -2440,10 +2440,17 @@ static int das_enqueue(pbrt_ctx *c, const pbrt_das_params *p, const float *dd, c
     const uint32_t blocks = DAS_XCDS * g.ntx * std::max(g.m, 1u);
 #endif
     const dim3 grid(blocks), block(64 * DAS_SPLIT);
-    if (p->interpolation == PBRT_DAS_NEAREST)
-        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_NEAREST>, grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, dout);
-    else
-        hipLaunchKernelGGL(k_das_beamform<PBRT_DAS_LINEAR>, grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, dout);
+    if (p->interpolation == PBRT_DAS_NEAREST) {
+        if (ttx)
+            hipLaunchKernelGGL((k_das_beamform<PBRT_DAS_NEAREST, true>), grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, ttx, dout);
+        else
+            hipLaunchKernelGGL((k_das_beamform<PBRT_DAS_NEAREST, false>), grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, ttx, dout);
+    } else {
+        if (ttx)
+            hipLaunchKernelGGL((k_das_beamform<PBRT_DAS_LINEAR, true>), grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, ttx, dout);
+        else
+            hipLaunchKernelGGL((k_das_beamform<PBRT_DAS_LINEAR, false>), grid, block, 0, c->stream, *p, g, dd, dt, de, dx, dz, ttx, dout);
+    }
     c->img_das_bytes = ((uint64_t)p->n_angles * p->n_elements * p->time_samples + (uint64_t)p->nx * p->nz) * 4;
     HIPCHK(c, hipGetLastError());
     return PBRT_OK;
@@ -2505,6 +2512,30 @@ int pbrt_das_beamform_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return das_enqueue(ctx, p, (const float *)d_data, (const float *)d_tx_delays, (const float *)d_elem_x, (const float *)d_x,
                        (const float *)d_z, (float *)d_out);
+}
+
+int pbrt_das_first_arrival_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_tx_delays, const void *d_elem_x, const void *d_x,
+                               const void *d_z, void *d_table) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, p && d_tx_delays && d_elem_x && d_x && d_z && d_table);
+    int rc = das_check(ctx, p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_das_first_arrival, dim3(div_up((uint64_t)p->nx * p->nz, 256)), dim3(256), 0, ctx->stream, *p, (const float *)d_tx_delays,
+                       (const float *)d_elem_x, (const float *)d_x, (const float *)d_z, (double *)d_table);
+    HIPCHK(ctx, hipGetLastError());
+    return PBRT_OK;
+}
+
+int pbrt_das_beamform_table_dev(pbrt_ctx *ctx, const pbrt_das_params *p, const void *d_data, const void *d_table, const void *d_elem_x,
+                                const void *d_x, const void *d_z, void *d_out) {
+    if (!ctx) return PBRT_E_INVALID;
+    NEED(ctx, p && d_data && d_table && d_elem_x && d_x && d_z && d_out);
+    int rc = das_check(ctx, p);
+    if (rc) return rc;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return das_enqueue(ctx, p, (const float *)d_data, nullptr, (const float *)d_elem_x, (const float *)d_x, (const float *)d_z,
+                       (float *)d_out, (const double *)d_table);
 }
 
 int pbrt_das_beamform(pbrt_ctx *ctx, const pbrt_das_params *p, const float *data, const float *tx_delays,

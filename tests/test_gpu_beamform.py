@@ -221,6 +221,15 @@ def test_image_formation_on_device_buffers_step_by_step(mi):
         assert np.array_equal(d_bf.numpy(), ref_bf) and np.array_equal(d_env.numpy(), ref_env) and np.array_equal(img, ref_img)
         assert st["measured"] & 0b1110 == 0b1110 and 0 < st["das_ms"] < 50 and 0 < st["envelope_ms"] < 50 and 0 < st["log_ms"] < 50
         assert st["das_model_bytes"] == (data.size + len(x) * len(z)) * 4
+        # the first-arrival table of the scan, made once: the same image bit for bit without the pass over all elements
+        tab = mi.das_first_arrival(tx, ex, x, z, c)
+        assert tab.shape == (5, len(x), len(z)) and tab.dtype == np.float64
+        d_bf2 = mi.das_beamform(d_data, tx, ex, x, z, fs, c, f_number=fnum, interpolation=interp, compound=comp, table=tab)
+        assert np.array_equal(d_bf2.numpy(), ref_bf)
+        t = tab.numpy()     # closed form of the plane-wave first arrival under the aperture: (x sin + z cos) / c
+        th = np.deg2rad(np.linspace(-12, 12, 5))
+        ix, iz = len(x) // 2, int(np.argmin(np.abs(z - 0.01)))   # (x - z tan(theta) inside the 7.7 mm array for every angle)
+        assert np.allclose(t[:, ix, iz], (x[ix] * np.sin(th) + z[iz] * np.cos(th)) / c, rtol=0, atol=1e-9)
     pulsed = mi.apply_pulse(d_data, fs, 5e6, 5 / (4 * 5e6))
     assert np.array_equal(pulsed.numpy(), mi.apply_pulse(data, fs, 5e6, 5 / (4 * 5e6)))
     with pytest.raises(RuntimeError):

@@ -25,5 +25,13 @@ for _ in range(N):
     st = cx.image_stats()
     for k in acc: acc[k] += st[k] / N
 h = lambda b: hashlib.md5(b.numpy().tobytes()).hexdigest()[:10]
-print(f"{os.environ.get('PBRT_HIP_LIB', 'default'):40s} {len(x)} x {len(z)}  das {acc['das_ms']*1e3:7.1f} us  envelope {acc['envelope_ms']*1e3:6.1f} us  "
-      f"log {acc['log_ms']*1e3:5.1f} us   md5 das {h(bf)} env {h(env)} img {h(img)}", flush=True)
+h_bf = h(bf)
+# with the first-arrival table of the scan made once (pbrt_das_first_arrival_dev / pbrt_das_beamform_table_dev)
+tab_ms = 0.0
+if hasattr(mi, "das_first_arrival"):
+    tab = mi.das_first_arrival(d["tx"], d["ex"], d["x"], d["z"], c)
+    for _ in range(N):
+        mi.das_beamform(d["data"], d["tx"], d["ex"], d["x"], d["z"], fs, c, out=bf, table=tab)
+        tab_ms += cx.image_stats()["das_ms"] / N
+print(f"{os.environ.get('PBRT_HIP_LIB', 'default'):40s} {len(x)} x {len(z)}  das {acc['das_ms']*1e3:7.1f} us (with table {tab_ms*1e3:6.1f} us, md5 {h(bf)})  envelope {acc['envelope_ms']*1e3:6.1f} us  "
+      f"log {acc['log_ms']*1e3:5.1f} us   md5 das {h_bf} env {h(env)} img {h(img)}", flush=True)

@@ -960,8 +960,9 @@ int oracle_scene_create(const pbrt_scene_desc *desc, oracle_scene **out) {
         if (p.type > PBRT_PRIM_CONE || p.material >= desc->n_materials ||
             (p.emitter >= 0 && (uint32_t)p.emitter >= desc->n_emitters) ||
             (p.type == PBRT_PRIM_CONE && !cone_frame(p, cc, ca, cb, cx))) {
+            const int rc = p.type > PBRT_PRIM_CONE ? PBRT_E_UNSUPPORTED : PBRT_E_INVALID;  // (p lives in *s)
             delete s;
-            return p.type > PBRT_PRIM_CONE ? PBRT_E_UNSUPPORTED : PBRT_E_INVALID;
+            return rc;
         }
     }
     s->sc.use_bvh = desc->accel == PBRT_ACCEL_BVH || desc->accel == PBRT_ACCEL_BVH_GLOBAL ||

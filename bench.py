@@ -532,6 +532,12 @@ def measure_usmain_loop(env, cfg, steps, warmup, with_cpu):
             img = iteration(ppr, 0.1 + 0.01 * i, acc)
         ctx.synchronize()
         dt = time.perf_counter() - t0
+        # the same loop with every call of the chain queued one by one (no recording): the before / after of the hipGraph replay
+        t0 = time.perf_counter()
+        for i in range(steps):
+            iteration(ppr, 0.1 + 0.01 * i, dict(update=0.0, render=0.0, acquire_kernel_ms=0.0), graph=False)
+        ctx.synchronize()
+        dt_plain = time.perf_counter() - t0
         # the same iteration with an event pair around every image-formation kernel (not part of the timed loop above)
         ctx.set_profiling(True)
         dev = dict(das_ms=0.0, envelope_ms=0.0, log_ms=0.0)
@@ -555,6 +561,8 @@ def measure_usmain_loop(env, cfg, steps, warmup, with_cpu):
         t_old = (time.perf_counter() - tb) / nold
         n_r = 2 * steps
         rec = {"paths_per_ray": ppr, "ms_per_iteration": round(dt / steps * 1e3, 4),
+               "renders_replayed_from_the_recording": int(acc.get("replayed", 0)), "renders": 2 * steps,
+               "ms_per_iteration_calls_queued_one_by_one": round(dt_plain / steps * 1e3, 4),
                "per_render_ms": {"params_update": round(acc["update"] / n_r * 1e3, 4), "acquire_queueing": round(acc["acquire"] / n_r * 1e3, 4),
                                  "image_formation_queueing": round(acc["queue"] / n_r * 1e3, 4),
                                  "wait_and_copy_of_the_image": round(acc["wait_copy"] / n_r * 1e3, 4)},

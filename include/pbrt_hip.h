@@ -541,6 +541,29 @@ typedef struct pbrt_image_stats {
 int pbrt_ctx_set_profiling(pbrt_ctx *ctx, int on);
 int pbrt_get_image_stats(pbrt_ctx *ctx, pbrt_image_stats *out);
 
+/* ---- the queued chain as ONE submission (hipGraph) ---------------------------------------------------------------------
+ * At the reference's own size (320 rays x 1 path, USMain.py:36) the chain above is eight small kernels, three fills and a copy:
+ * the host spends as long queueing them as the device spends running them, 100 times per script.  Between
+ * pbrt_ctx_record_begin and pbrt_ctx_record_end the queueing entry points (pbrt_us_acquire_queue_dev, pbrt_us_apply_pulse_dev,
+ * pbrt_das_beamform_dev, pbrt_das_beamform_table_dev, pbrt_envelope_dev, pbrt_log_compress_dev) are RECORDED on the context's
+ * stream instead of run; pbrt_graph_launch replays the recording in one submission and returns without waiting, exactly as if
+ * the recorded calls had just been made: same kernels, same arguments, same results bit for bit, the acquisition's statistics
+ * arrive with the next call that waits (kernel_ms / bounce_ms are 0: a replay carries no event pairs).
+ *  - Arguments are frozen at recording time: parameter blocks, seeds, path counts and every device pointer.  What the kernels
+ *    READ through those pointers is not: pbrt_scene_update_material between two launches is seen by the second one (the
+ *    finite-difference loop of USMain.py:262-289 changes one roughness per render and nothing else).
+ *  - The workspace must be warm: run the chain once the ordinary way first; a recorded call that would have to allocate, or to
+ *    upload a table, fails with PBRT_E_INVALID.  Any other entry point on the context fails with PBRT_E_INVALID while a
+ *    recording is open.  An error inside a recording leaves it open: close it with pbrt_ctx_record_end (which then reports it).
+ *  - A recording goes stale when the context frees or replaces memory it refers to (a larger request for the same workspace
+ *    buffer, pbrt_ctx_trim, pbrt_dev_free, pbrt_scene_destroy) or uploads other acquisition tables: pbrt_graph_launch then
+ *    returns PBRT_E_INVALID and launches nothing; record again. */
+typedef struct pbrt_graph pbrt_graph;
+int pbrt_ctx_record_begin(pbrt_ctx *ctx);
+int pbrt_ctx_record_end(pbrt_ctx *ctx, pbrt_graph **out);
+int pbrt_graph_launch(pbrt_graph *g);
+int pbrt_graph_destroy(pbrt_graph *g);
+
 #ifdef __cplusplus
 }
 #endif

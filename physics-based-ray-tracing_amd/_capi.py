@@ -204,6 +204,10 @@ SIGNATURES = {
     "pbrt_dev_download": (C.c_int, [_P, _F, _P, C.c_uint64]),
     "pbrt_ctx_set_profiling": (C.c_int, [_P, C.c_int]),
     "pbrt_get_image_stats": (C.c_int, [_P, C.POINTER(ImageStats)]),
+    "pbrt_ctx_record_begin": (C.c_int, [_P]),
+    "pbrt_ctx_record_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "pbrt_graph_launch": (C.c_int, [_P]),
+    "pbrt_graph_destroy": (C.c_int, [_P]),
 }
 
 _lib = None
@@ -344,11 +348,17 @@ class Context:
     def set_profiling(self, on: bool) -> None:
         """HIP-event pairs around the image-formation steps (pbrt_get_image_stats); off by default"""
         self.check(self.lib.pbrt_ctx_set_profiling(self.handle, int(bool(on))), "pbrt_ctx_set_profiling")
+        self.profiling = bool(on)
 
     def image_stats(self) -> dict:
         st = ImageStats()
         self.check(self.lib.pbrt_get_image_stats(self.handle, C.byref(st)), "pbrt_get_image_stats")
         return {k: getattr(st, k) for k, _ in st._fields_ if k != "pad"}
+
+    def record(self) -> "Recording":
+        """with ctx.record() as rec: <queueing calls> -- the calls are recorded instead of run (pbrt_ctx_record_begin / _end);
+        rec.graph.launch() replays them in one submission"""
+        return Recording(self)
 
     def close(self):
         if getattr(self, "handle", None):
@@ -360,6 +370,52 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class Graph:
+    """A recorded chain of queued calls (pbrt_graph): launch() submits all of it at once and returns without waiting."""
+
+    def __init__(self, ctx: Context, handle):
+        self.ctx = ctx
+        self.handle = handle
+
+    def launch(self) -> None:
+        self.ctx.check(self.ctx.lib.pbrt_graph_launch(self.handle), "pbrt_graph_launch")
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx.lib.pbrt_graph_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Recording:
+    """Context manager around pbrt_ctx_record_begin / pbrt_ctx_record_end; `graph` is set when the block ends without an error
+    (an exception inside the block still closes the recording, and is re-raised)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.graph = None
+
+    def __enter__(self):
+        self.ctx.check(self.ctx.lib.pbrt_ctx_record_begin(self.ctx.handle), "pbrt_ctx_record_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = _P()
+        rc = self.ctx.lib.pbrt_ctx_record_end(self.ctx.handle, C.byref(h))
+        if et is not None:
+            if rc == 0:
+                self.ctx.lib.pbrt_graph_destroy(h)
+            return False
+        self.ctx.check(rc, "pbrt_ctx_record_end")
+        self.graph = Graph(self.ctx, h)
+        return False
 
 
 class DeviceBuffer:

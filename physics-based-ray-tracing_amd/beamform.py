@@ -250,10 +250,12 @@ class _RenderPlan:
         self.d_env = _capi.DeviceBuffer(cx, (nx, nz))
         self.d_img = _capi.DeviceBuffer(cx, (nx, nz))
         self.d_table = _capi.DeviceBuffer(cx, (A, nx, nz), np.float64)   # first-arrival times of this scan (das_first_arrival)
+        # the queued chain of one key as a recording (pbrt_graph), made at the second call in a row with that key
+        self.graph = self.graph_key = self.warm_key = None
 
 
 def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range=60.0, step=None, seed=None,
-              paths_per_ray=None, beamformer=None, device_resident=True, return_bmode=True, timing=None):
+              paths_per_ray=None, beamformer=None, device_resident=True, return_bmode=True, timing=None, graph=True):
     """The reference's us_render (USMain.py:93-224) without the plotting: acquisition -> DAS -> envelope -> log
     compression.  Returns (display_image [nz, nx] in [0, 1], bmode envelope [nx, nz] (None with return_bmode=False),
     (x_scan, z_scan)).
@@ -262,7 +264,10 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
     kernels are queued behind it on the context's stream (*_dev entry points, ABI 5), and ONE copy brings the display image to
     the host (a second one the envelope, if asked for).  `integrator.channel_buf` is fetched only if somebody reads it.
     device_resident=False is round 4's path through the host-pointer entry points (every step up and down PCIe), kept for the
-    A/B and the bit-for-bit test.  timing: a dict that receives host wall-clock seconds (acquire, queue, wait_copy)."""
+    A/B and the bit-for-bit test.  timing: a dict that receives host wall-clock seconds (acquire, queue, wait_copy).
+    graph (default): from the third call in a row with the same arguments on, the queued calls are replayed from a recording
+    (pbrt_ctx_record_begin / pbrt_graph_launch: one submission instead of eleven; same kernels, same bits); graph=False, or a
+    context that profiles (Context.set_profiling), queues them one by one."""
     import time as _time
     integ = scene.integrator()
     A, E, T = integ.n_angles, integ.n_elements, integ.time_samples
@@ -299,31 +304,74 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
         plan = _RenderPlan(cx, A, E, T, probe.geometry[0], x_scan, z_scan, gaussian)
         plan.key = key
         integ._render_plan = plan
-    t0 = _time.perf_counter()
-    integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed, out_dev=plan.d_channel.ptr, pulse=False,
-                   queue=True)                                                                          # :99 (queued, not waited for)
-    t1 = _time.perf_counter()
-    delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)                 # :121
-    if plan.tx_host is None or not np.array_equal(plan.tx_host, delays):
-        plan.d_tx.upload(delays)
-        plan.tx_host = delays.copy()
-        # the scan's first-arrival times follow the delays and the grid: made again only when those change (never, in the loop
-        # of USMain.py:262-289)
-        das_first_arrival(plan.d_tx, plan.d_ex, plan.d_x, plan.d_z, integ.sound_speed, out=plan.d_table)
-    rf = plan.d_channel
-    if gaussian:                                                                                       # f-3: carrier on the device
-        rf = apply_pulse(plan.d_channel, integ.fs, integ.frequency, integ.pulse_sigma, out=plan.d_rf)
-    integ._set_device_channel(rf)
-    bf.automatic_setup(info(plan.d_tx), probe)                                                         # :175
+    rf = plan.d_rf if gaussian else plan.d_channel
     scan.d_x, scan.d_z = plan.d_x, plan.d_z
     bf.probe_dev = plan.d_ex
-    d_bf = bf.beamform(rf, scan, out=plan.d_bf, table=plan.d_table)                                    # :204
-    d_env = bf.compute_envelope(d_bf, scan, out=plan.d_env)                                            # :205
-    d_img = log_compress(d_env, dynamic_range, out=plan.d_img)                                         # :210-218
+
+    def queue_acquisition():
+        integ._acquire(scene, integ.quirks, paths_per_ray=paths_per_ray, seed=seed, out_dev=plan.d_channel.ptr, pulse=False,
+                       queue=True)                                                                      # :99 (queued, not waited for)
+
+    def queue_image_formation():
+        if gaussian:                                                                                   # f-3: carrier on the device
+            apply_pulse(plan.d_channel, integ.fs, integ.frequency, integ.pulse_sigma, out=plan.d_rf)
+        bf.automatic_setup(info(plan.d_tx), probe)                                                     # :175
+        bf.beamform(rf, scan, out=plan.d_bf, table=plan.d_table)                                       # :204
+        bf.compute_envelope(plan.d_bf, scan, out=plan.d_env)                                           # :205
+        log_compress(plan.d_env, dynamic_range, out=plan.d_img)                                        # :210-218
+
+    # What the queued calls depend on besides the CONTENTS of device memory: a recording of them (pbrt_ctx_record_begin, one
+    # hipGraph) stands for exactly this key.  The reference's loop (USMain.py:262-289) repeats one key 100 times and changes a
+    # material's roughness in between (pbrt_scene_update_material writes device memory: the replay sees it).
+    t0 = _time.perf_counter()
+    gkey = None
+    if graph and not getattr(cx, "profiling", False):
+        h = scene.device().handle
+        gkey = (bytes(integ.us_params(scene, integ.quirks)), getattr(h, "value", h),
+                int(integ.seed if seed is None else seed) & 0xFFFFFFFF,
+                int(paths_per_ray if paths_per_ray is not None else integ.paths_per_ray), float(dynamic_range),
+                tuple(sorted(bf.setups.items())), float(integ.pulse_sigma) if gaussian else None)
+    replayed = False
+    if gkey is not None and plan.graph is not None and plan.graph_key == gkey:
+        try:
+            plan.graph.launch()
+            replayed = True
+        except RuntimeError:        # stale (the context freed or replaced memory the recording refers to): queue it the plain way
+            plan.graph = plan.graph_key = None
+    if replayed:
+        integ.transmission_delays_buf = plan.tx_host.reshape(-1).copy()
+        integ._ray_count = None
+        integ._stats_ctx = cx
+        bf.automatic_setup(info(plan.d_tx), probe)
+        t1 = _time.perf_counter()
+    else:
+        queue_acquisition()
+        t1 = _time.perf_counter()
+        delays = np.asarray(integ.transmission_delays_buf, dtype=np.float32).reshape(A, E)             # :121
+        if plan.tx_host is None or not np.array_equal(plan.tx_host, delays):
+            plan.d_tx.upload(delays)
+            plan.tx_host = delays.copy()
+            # the scan's first-arrival times follow the delays and the grid: made again only when those change (never, in the
+            # loop of USMain.py:262-289)
+            das_first_arrival(plan.d_tx, plan.d_ex, plan.d_x, plan.d_z, integ.sound_speed, out=plan.d_table)
+            plan.graph = plan.graph_key = plan.warm_key = None
+        queue_image_formation()
+        if gkey is not None and plan.warm_key == gkey:
+            # the second call in a row with this key: the workspace is warm, record the chain for the calls that follow
+            try:
+                with cx.record() as rec:
+                    queue_acquisition()
+                    queue_image_formation()
+                plan.graph, plan.graph_key = rec.graph, gkey
+            except RuntimeError:
+                plan.graph = plan.graph_key = None
+        plan.warm_key = gkey
+    integ._set_device_channel(rf)
+    d_env, d_img = plan.d_env, plan.d_img
     t2 = _time.perf_counter()
     display = d_img.numpy().T                                                                          # :221  (the one copy)
     bmode = d_env.numpy() if return_bmode else None
     t3 = _time.perf_counter()
     if timing is not None:
-        timing.update(acquire=t1 - t0, queue=t2 - t1, wait_copy=t3 - t2)
+        timing.update(acquire=t1 - t0, queue=t2 - t1, wait_copy=t3 - t2, replayed=replayed)
     return display, bmode, (x_scan, z_scan)

@@ -50,7 +50,10 @@ struct pbrt_ctx {
     void release(const char *name) {
         auto it = ws.find(name);
         if (it == ws.end()) return;
-        if (it->second.p) (void)hipFree(it->second.p);
+        if (it->second.p) {
+            (void)hipFree(it->second.p);
+            ++ws_epoch;
+        }
         ws.erase(it);
     }
     std::vector<hipEvent_t> ev_pool;
@@ -59,6 +62,7 @@ struct pbrt_ctx {
     // stream or starts other work on the context finishes it first (ctx_settle).
     struct PendingAcq {
         bool active = false, streams = false, tab0 = false;
+        bool timed = true;  // false: replayed from a recording (no event pairs; kernel_ms / bounce_ms are 0)
         size_t n_ev = 0;
         uint32_t passes = 0, launches = 0;
         uint64_t samples = 0, nchan = 0;
@@ -82,6 +86,13 @@ struct pbrt_ctx {
     bool img_event(int i) { return img_ev[i] || hipEventCreate(&img_ev[i]) == hipSuccess; }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t lds_limit = 0;
+    // A recording of the queued chain (pbrt_ctx_record_begin .. pbrt_ctx_record_end; replayed by pbrt_graph_launch): while it is
+    // open the context's stream captures instead of running, nothing may wait for it, allocate or upload.  ws_epoch counts the
+    // events that make a finished recording stale: memory it may refer to freed or replaced, other acquisition tables uploaded,
+    // the envelope's tap table made for another column length.
+    bool recording = false;
+    uint64_t ws_epoch = 0;
+    uint32_t n_graphs = 0;
 
     int fail(int code, const char *fmt, ...) {
         char buf[1024];
@@ -98,7 +109,14 @@ struct pbrt_ctx {
         b.need = bytes;
         b.stamp = call_seq;
         if (b.bytes >= bytes && b.p) return b.p;
-        if (b.p) (void)hipFree(b.p);
+        if (recording) {  // (the caller reports PBRT_E_NOMEM with this message)
+            fail(PBRT_E_NOMEM, "recording: workspace buffer %s (%zu bytes) is not there yet -- run the chain once before recording it", name, bytes);
+            return nullptr;
+        }
+        if (b.p) {
+            (void)hipFree(b.p);
+            ++ws_epoch;
+        }
         b.p = nullptr;
         b.bytes = 0;
         // small buffers get 12.5 % of slack (a slightly larger request re-uses them); the large ones -- path state, ray and
@@ -107,7 +125,10 @@ struct pbrt_ctx {
         if (ws_limit && ws_total() + want > ws_limit) {  // make room: what this call has not asked for goes first
             for (auto it = ws.begin(); it != ws.end();) {
                 if (it->second.stamp != call_seq && &it->second != &b) {
-                    if (it->second.p) (void)hipFree(it->second.p);
+                    if (it->second.p) {
+                        (void)hipFree(it->second.p);
+                        ++ws_epoch;
+                    }
                     it = ws.erase(it);
                 } else {
                     ++it;
@@ -166,10 +187,22 @@ struct pbrt_scene {
         if (!(cond)) return (ctx)->fail(PBRT_E_INVALID, "invalid argument: %s", #cond); \
     } while (0)
 
+// entry points that wait, copy from host memory or free: not while the context's stream records (pbrt_ctx_record_begin)
+#define NOT_RECORDING(ctx)                                                                                                   \
+    do {                                                                                                                     \
+        if ((ctx)->recording)                                                                                                \
+            return (ctx)->fail(PBRT_E_INVALID, "a recording is open on this context (pbrt_ctx_record_begin): %s cannot run", __func__); \
+    } while (0)
+
 // finishes an acquisition that was queued without waiting (pbrt_us_acquire_queue_dev): waits for the stream, checks the guard words,
 // fills pbrt_stats.  Called first by every entry point that waits for the stream or starts other work on the context.
 static int us_finish(pbrt_ctx *c);
-static inline int ctx_settle(pbrt_ctx *c) { return c->pend.active ? us_finish(c) : PBRT_OK; }
+static inline int ctx_settle(pbrt_ctx *c) {
+    // (every entry point that waits for the stream or starts work of its own comes through here: none of them may run while the
+    // stream records -- a wait would invalidate the capture)
+    if (c->recording) return c->fail(PBRT_E_INVALID, "a recording is open on this context (pbrt_ctx_record_begin): only the queueing entry points may be called");
+    return c->pend.active ? us_finish(c) : PBRT_OK;
+}
 
 template <typename T>
 static int upload(pbrt_scene *s, const T *src, size_t n, const T **dst) {
@@ -388,7 +421,10 @@ int pbrt_ctx_trim(pbrt_ctx *c, uint64_t *held_after) {
         DevBuf &b = it->second;
         const size_t fit = b.need < (size_t(64) << 20) ? b.need + b.need / 8 + 256 : b.need + 256;
         if (b.stamp != c->call_seq || b.bytes > fit || !b.p) {
-            if (b.p) (void)hipFree(b.p);
+            if (b.p) {
+                (void)hipFree(b.p);
+                ++c->ws_epoch;
+            }
             it = c->ws.erase(it);
         } else {
             ++it;
@@ -409,6 +445,7 @@ int pbrt_get_stats(pbrt_ctx *c, pbrt_stats *out) {
 int pbrt_scene_create(pbrt_ctx *c, const pbrt_scene_desc *d, pbrt_scene **out) {
     if (!c) return PBRT_E_INVALID;
     NEED(c, d && out);
+    NOT_RECORDING(c);
     NEED(c, d->n_prims > 0 && d->prims && d->n_materials > 0 && d->materials);
     NEED(c, d->n_emitters == 0 || d->emitters);
     NEED(c, d->n_light_prims == 0 || (d->light_prims && d->light_cdf));
@@ -536,6 +573,7 @@ int pbrt_scene_update_material(pbrt_scene *s, uint32_t index, const pbrt_materia
     if (!s) return PBRT_E_INVALID;
     pbrt_ctx *c = s->ctx;
     NEED(c, m && index < s->n_mats);
+    NOT_RECORDING(c);  // (a recorded copy would replay the bytes of THIS call's host block)
     HIPCHK(c, hipSetDevice(c->device));
     // in the order of the context's stream: behind an acquisition that is still queued, ahead of the next one (the 32 bytes are
     // staged before the call returns)
@@ -545,9 +583,11 @@ int pbrt_scene_update_material(pbrt_scene *s, uint32_t index, const pbrt_materia
 
 int pbrt_scene_destroy(pbrt_scene *s) {
     if (!s) return PBRT_OK;
+    NOT_RECORDING(s->ctx);
     (void)hipSetDevice(s->ctx->device);
     (void)ctx_settle(s->ctx);
     (void)hipStreamSynchronize(s->ctx->stream);  // queued work may still read the scene
+    ++s->ctx->ws_epoch;
     for (void *p : s->allocs) (void)hipFree(p);
     delete s;
     return PBRT_OK;
@@ -1841,7 +1881,12 @@ extern "C" {
 static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32_t ppr, uint32_t path_offset,
                    uint32_t norm_paths, float *d_channel, float *tx_host, bool wait = true) {
     pbrt_ctx *c = s->ctx;
-    if (int rcs = ctx_settle(c)) return rcs;
+    if (c->recording) {  // recorded, not run: the queueing form only, one acquisition per recording
+        if (wait || c->pend.active) return c->fail(PBRT_E_INVALID, "recording: one pbrt_us_acquire_queue_dev per recording, and no call that waits");
+    } else if (int rcs = ctx_settle(c)) {
+        return rcs;
+    }
+    const bool timed = !c->recording;  // (event pairs recorded into a graph cannot be read back)
     NEED(c, p && d_channel);
     NEED(c, p->n_angles > 0 && p->n_angles <= PBRT_US_MAX_ANGLES && p->n_elements > 0 && p->time_samples > 0);
     NEED(c, (uint64_t)p->n_angles * p->n_elements * p->time_samples < 0xffffffffull);  // channel index is 32-bit (echo bins)
@@ -1964,6 +2009,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         std::copy(dir0.begin(), dir0.end(), img.begin() + n_rays);
         std::copy(ex.begin(), ex.end(), img.begin() + n_rays + 3 * NA);
         if (c->us_tab_dev != (const void *)tabs || c->us_tab_host != img) {
+            if (c->recording) return c->fail(PBRT_E_INVALID, "recording: the acquisition's tables are not on the device yet -- run the chain once before recording it");
+            ++c->ws_epoch;  // (a finished recording was made with the tables that are replaced now)
             HIPCHK(c, hipMemcpyAsync(tabs, img.data(), img.size() * 4, hipMemcpyHostToDevice, st));
             c->us_tab_host.swap(img);
             c->us_tab_dev = tabs;
@@ -1972,7 +2019,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     const size_t nchan = (size_t)n_rays * T;
     HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
     HIPCHK(c, hipMemsetAsync(dstats, 0, 512 + segstats_bytes, st));
-    HIPCHK(c, hipEventRecord(c->ev0, st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev0, st));
     UsArgs a{};
     a.sc = s->ds;
     a.p = *p;
@@ -2031,9 +2078,9 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
             hipEvent_t e0 = c->event(n_ev);
             if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
             n_ev += 2;
-            HIPCHK(c, hipEventRecord(e0, st));
+            if (timed) HIPCHK(c, hipEventRecord(e0, st));
             if ((rc = us_wf_pass(s, a, wfb, wfp, nseg_pass, &launches)) != 0) return rc;
-            HIPCHK(c, hipEventRecord(pass_e1, st));
+            if (timed) HIPCHK(c, hipEventRecord(pass_e1, st));
             continue;
         }
         float *in = stA, *out = stB;
@@ -2050,7 +2097,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
                 hipEvent_t e0 = c->event(n_ev);
                 if (!e0 || !pass_e1) return c->fail(PBRT_E_DEVICE, "hipEventCreate failed");
                 n_ev += 2;
-                HIPCHK(c, hipEventRecord(e0, st));
+                if (timed) HIPCHK(c, hipEventRecord(e0, st));
             }
             bool first_kernel = depth == 0;
             if (depth == 0 && emit && !emit_fused) {
@@ -2072,12 +2119,12 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
             std::swap(in, out);
             std::swap(sin, sout);
         }
-        HIPCHK(c, hipEventRecord(pass_e1, st));
+        if (timed) HIPCHK(c, hipEventRecord(pass_e1, st));
     }
     const float inv_norm = 1.0f / (float)(norm_paths ? norm_paths : 1);
     hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(c->ev1, st));
+    if (timed) HIPCHK(c, hipEventRecord(c->ev1, st));
     hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
     HIPCHK(c, hipGetLastError());
     // counters and guard words into the context's pinned page (queued copies), read by us_finish once the stream has drained
@@ -2085,6 +2132,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if (streams && (rc = wf_guard_fetch(c, c->pin_guard())) != 0) return rc;
     pbrt_ctx::PendingAcq &P = c->pend;
     P.active = true;
+    P.timed = timed;
     P.streams = streams;
     P.tab0 = a.first_hit != nullptr;
     P.n_ev = n_ev;
@@ -2107,9 +2155,9 @@ static int us_finish(pbrt_ctx *c) {
     if (P.streams && (rc = wf_check_guard(c, c->pin_guard())) != 0) return rc;
     const unsigned long long *hstats = c->pin_stats();
     float ms = 0.0f;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (P.timed) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;
-    for (size_t i = 0; i + 1 < P.n_ev; i += 2) {
+    for (size_t i = 0; P.timed && i + 1 < P.n_ev; i += 2) {
         float t = 0.0f;
         HIPCHK(c, hipEventElapsedTime(&t, c->ev_pool[i], c->ev_pool[i + 1]));
         bounce_ms += t;
@@ -2241,6 +2289,7 @@ extern "C" {
     pbrt_ctx *c = (ctxp);                      \
     if (!c) return PBRT_E_INVALID;             \
     if (n == 0) return PBRT_OK;                \
+    NOT_RECORDING(c);                          \
     HIPCHK(c, hipSetDevice(c->device));        \
     Stage S(c, "leaf_io", (total_bytes));      \
     if (S.rc) return S.rc;                     \
@@ -2406,10 +2455,10 @@ struct ImgTimer {
     pbrt_ctx *c;
     int slot;
     ImgTimer(pbrt_ctx *ctx, int s) : c(ctx), slot(s) {
-        if (c->profiling && c->img_event(2 * slot)) (void)hipEventRecord(c->img_ev[2 * slot], c->stream);
+        if (c->profiling && !c->recording && c->img_event(2 * slot)) (void)hipEventRecord(c->img_ev[2 * slot], c->stream);
     }
     ~ImgTimer() {
-        if (c->profiling && c->img_event(2 * slot + 1)) {
+        if (c->profiling && !c->recording && c->img_event(2 * slot + 1)) {
             (void)hipEventRecord(c->img_ev[2 * slot + 1], c->stream);
             c->img_mask |= 1u << slot;
         }
@@ -2463,6 +2512,7 @@ static int env_enqueue(pbrt_ctx *c, uint32_t nx, uint32_t nz, const float *din, 
     if (!taps) return PBRT_E_NOMEM;
     ImgTimer tm(c, IMG_ENV);
     if (fresh || c->env_taps_n != nz) {
+        ++c->ws_epoch;  // (a finished recording holds no launch of this kernel: its taps are replaced now)
         hipLaunchKernelGGL(k_hilbert_taps, dim3(div_up(G, 256)), dim3(256), 0, c->stream, nz, taps);
         c->env_taps_n = nz;
     }
@@ -2637,6 +2687,7 @@ int pbrt_us_apply_pulse(pbrt_ctx *ctx, uint32_t n_traces, uint32_t time_samples,
 // ---- device buffers and the stream (ABI 5): what a caller needs to keep the us_render loop in HBM without another GPU library ----
 int pbrt_ctx_synchronize(pbrt_ctx *c) {
     if (!c) return PBRT_E_INVALID;
+    NOT_RECORDING(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ctx_settle(c);  // (a queued acquisition: its guard words are looked at now)
@@ -2652,6 +2703,7 @@ int pbrt_ctx_set_profiling(pbrt_ctx *c, int on) {
 int pbrt_get_image_stats(pbrt_ctx *c, pbrt_image_stats *out) {
     if (!c || !out) return PBRT_E_INVALID;
     std::memset(out, 0, sizeof *out);
+    NOT_RECORDING(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     double *slot[IMG_STEPS] = {&out->pulse_ms, &out->das_ms, &out->envelope_ms, &out->log_ms};
@@ -2683,9 +2735,11 @@ int pbrt_dev_alloc(pbrt_ctx *c, uint64_t bytes, void **out) {
 int pbrt_dev_free(pbrt_ctx *c, void *p) {
     if (!c) return PBRT_E_INVALID;
     if (!p) return PBRT_OK;
+    NOT_RECORDING(c);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // queued work may still read or write it
     (void)ctx_settle(c);
+    ++c->ws_epoch;  // (a recording may hold this pointer)
     HIPCHK(c, hipFree(p));
     return PBRT_OK;
 }
@@ -2694,6 +2748,7 @@ int pbrt_dev_upload(pbrt_ctx *c, void *dst_dev, const void *src_host, uint64_t b
     if (!c) return PBRT_E_INVALID;
     NEED(c, (dst_dev && src_host) || bytes == 0);
     if (!bytes) return PBRT_OK;
+    NOT_RECORDING(c);
     HIPCHK(c, hipSetDevice(c->device));
     // in stream order behind the queued kernels; a pageable source is staged before the call returns, so the caller may reuse it
     HIPCHK(c, hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
@@ -2703,10 +2758,91 @@ int pbrt_dev_upload(pbrt_ctx *c, void *dst_dev, const void *src_host, uint64_t b
 int pbrt_dev_download(pbrt_ctx *c, void *dst_host, const void *src_dev, uint64_t bytes) {
     if (!c) return PBRT_E_INVALID;
     NEED(c, (dst_host && src_dev) || bytes == 0);
+    NOT_RECORDING(c);
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes) HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return ctx_settle(c);  // an acquisition queued ahead of this copy that tripped its guard makes the copy's content invalid
+}
+
+// ---- the queued chain as one submission (include/pbrt_hip.h) ------------------------------------------------------------------
+struct pbrt_graph {
+    pbrt_ctx *ctx = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    pbrt_ctx::PendingAcq pend;  // what the recorded acquisition leaves for us_finish (inactive: the recording holds none)
+    uint64_t epoch = 0;         // ctx->ws_epoch at the end of the recording
+    uint64_t das_bytes = 0;
+};
+
+int pbrt_ctx_record_begin(pbrt_ctx *c) {
+    if (!c) return PBRT_E_INVALID;
+    if (int rc = ctx_settle(c)) return rc;  // (also: no recording inside a recording)
+    HIPCHK(c, hipSetDevice(c->device));
+    // relaxed: the recorded entry points query function attributes and free memory, calls a stricter mode refuses on any thread
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
+    c->recording = true;
+    return PBRT_OK;
+}
+
+int pbrt_ctx_record_end(pbrt_ctx *c, pbrt_graph **out) {
+    if (!c || !out) return PBRT_E_INVALID;
+    *out = nullptr;
+    if (!c->recording) return c->fail(PBRT_E_INVALID, "pbrt_ctx_record_end without pbrt_ctx_record_begin");
+    c->recording = false;
+    pbrt_ctx::PendingAcq P = c->pend;
+    c->pend.active = false;  // (nothing ran)
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(c->stream, &g);
+    if (e != hipSuccess || !g) {
+        (void)hipGetLastError();
+        return c->fail(PBRT_E_DEVICE, "hipStreamEndCapture: %s (a call inside the recording failed or waited)", hipGetErrorString(e));
+    }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphDestroy(g);
+        return c->fail(PBRT_E_DEVICE, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    pbrt_graph *G = new pbrt_graph;
+    G->ctx = c;
+    G->graph = g;
+    G->exec = x;
+    G->pend = P;
+    G->pend.timed = false;
+    G->epoch = c->ws_epoch;
+    G->das_bytes = c->img_das_bytes;
+    ++c->n_graphs;
+    *out = G;
+    return PBRT_OK;
+}
+
+int pbrt_graph_launch(pbrt_graph *G) {
+    if (!G) return PBRT_E_INVALID;
+    pbrt_ctx *c = G->ctx;
+    if (int rc = ctx_settle(c)) return rc;
+    if (G->epoch != c->ws_epoch)
+        return c->fail(PBRT_E_INVALID, "the recording is stale: memory or tables it refers to were freed or replaced since it was made; record again");
+    HIPCHK(c, hipSetDevice(c->device));
+    ++c->call_seq;
+    for (auto &kv : c->ws) kv.second.stamp = c->call_seq;  // (a trim between launches must not take what the replay uses)
+    HIPCHK(c, hipGraphLaunch(G->exec, c->stream));
+    c->pend = G->pend;
+    c->img_das_bytes = G->das_bytes;
+    return PBRT_OK;
+}
+
+int pbrt_graph_destroy(pbrt_graph *G) {
+    if (!G) return PBRT_OK;
+    pbrt_ctx *c = G->ctx;
+    (void)hipSetDevice(c->device);
+    if (!c->recording) (void)hipStreamSynchronize(c->stream);  // a replay may still run
+    if (G->exec) (void)hipGraphExecDestroy(G->exec);
+    if (G->graph) (void)hipGraphDestroy(G->graph);
+    if (c->n_graphs) --c->n_graphs;
+    delete G;
+    return PBRT_OK;
 }
 
 }  // extern "C"

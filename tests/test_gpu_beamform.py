@@ -180,7 +180,7 @@ def test_device_resident_chain_equals_the_host_chain_bit_for_bit(mi):
         d_dev, b_dev, (xs, zs) = mi.us_render(sc, timing=tm, **kw)
         assert ui._channel_host is None and ui._channel_dev is not None        # nothing but the two images crossed PCIe
         assert d_dev.shape == (len(zs), len(xs)) and b_dev.shape == (len(xs), len(zs))
-        assert set(tm) == {"acquire", "queue", "wait_copy"} and all(v >= 0 for v in tm.values())
+        assert set(tm) == {"acquire", "queue", "wait_copy", "replayed"} and all(v >= 0 for v in tm.values()) and not tm["replayed"]
         chan = ui.channel_buf                                                   # the lazy copy happens here
         assert chan.shape == (5, 64, 10000) and ui._channel_host is not None and np.abs(chan).max() > 0
         probe = mi.build_probe("linear", 64, ui.pitch, ui.frequency, 70)
@@ -276,3 +276,118 @@ def test_a_queued_acquisition_reports_with_the_next_waiting_call(mi, capi):
     params[key] = 0.7
     params.update()
     assert np.allclose(ui._acquire(sc, ui.quirks), ref, rtol=2e-5, atol=1e-7 * np.abs(ref).max())
+
+
+def test_recorded_chain_replays_the_queued_calls(mi, capi):
+    """pbrt_ctx_record_begin / _end / pbrt_graph_launch: the image-formation calls recorded on device buffers and replayed give
+    the images of the plain calls bit for bit, also after the input buffer's CONTENTS changed; what may not run inside a recording
+    says so and leaves it usable; a recording whose memory the context gave away refuses to launch."""
+    cx = mi.default_context()
+    data, tx, ex, c, fs = _rand_case(31, 5, 64, 4000, c=1540.0, fs=50e6, pitch=1.2e-4)
+    lam = 1540.0 / 5e6
+    x = np.arange(-0.01, 0.01 + lam / 4, lam / 4)
+    z = np.arange(0.001, 0.03 + lam / 4, lam / 4)
+    d_data = mi.DeviceBuffer.from_host(cx, data)
+    tab = mi.das_first_arrival(tx, ex, x, z, c)
+    d_tx, d_ex = mi.DeviceBuffer.from_host(cx, tx), mi.DeviceBuffer.from_host(cx, ex)
+    d_x, d_z = mi.DeviceBuffer.from_host(cx, x.astype(np.float32)), mi.DeviceBuffer.from_host(cx, z.astype(np.float32))
+    d_bf, d_env, d_img = (mi.DeviceBuffer(cx, (len(x), len(z))) for _ in range(3))
+
+    def chain():
+        mi.das_beamform(d_data, d_tx, d_ex, d_x, d_z, fs, c, out=d_bf, table=tab)
+        mi.envelope(d_bf, out=d_env)
+        mi.log_compress(d_env, 50.0, out=d_img)
+
+    chain()                                                     # warm: the tap table and the block maxima exist now
+    ref_env, ref_img = d_env.numpy(), d_img.numpy()
+    with cx.record() as rec:
+        chain()
+        with pytest.raises(RuntimeError, match="recording"):
+            cx.synchronize()                                    # nothing may wait inside a recording ...
+        with pytest.raises(RuntimeError, match="recording"):
+            d_img.numpy()
+        with pytest.raises(RuntimeError, match="recording"):
+            d_data.upload(data)
+    g = rec.graph                                               # ... and the recording survived the refusals
+    d_env.upload(np.zeros_like(ref_env))
+    d_img.upload(np.zeros_like(ref_img))
+    g.launch()
+    assert np.array_equal(d_env.numpy(), ref_env) and np.array_equal(d_img.numpy(), ref_img)
+    data2 = data[:, ::-1].copy()
+    d_data.upload(data2)                                        # same pointers, other contents: the replay reads what is there now
+    g.launch()
+    got = d_img.numpy()
+    d_data2 = mi.DeviceBuffer.from_host(cx, data2)
+    mi.das_beamform(d_data2, d_tx, d_ex, d_x, d_z, fs, c, out=d_bf, table=tab)
+    mi.envelope(d_bf, out=d_env)
+    mi.log_compress(d_env, 50.0, out=d_img)
+    assert np.array_equal(got, d_img.numpy()) and not np.array_equal(got, ref_img)
+    # an envelope of another column length replaces the context's tap table: the recording is stale and says so
+    mi.envelope(np.ones((2, 100), np.float32))
+    with pytest.raises(RuntimeError, match="stale"):
+        g.launch()
+    g.close()
+    # a recording that would have to allocate fails inside (a fresh context: no tap table yet), and the context works afterwards
+    cx2 = capi.Context(cx.device)
+    d_a, d_b = mi.DeviceBuffer.from_host(cx2, np.ones((3, 100), np.float32)), mi.DeviceBuffer(cx2, (3, 100))
+    with pytest.raises(RuntimeError, match="run the chain once"):
+        with cx2.record():
+            mi.envelope(d_a, out=d_b)
+    mi.envelope(d_a, out=d_b)
+    with cx2.record() as rec2:
+        mi.envelope(d_a, out=d_b)
+    d_b.upload(np.zeros((3, 100), np.float32))
+    rec2.graph.launch()
+    assert np.allclose(d_b.numpy(), mi.envelope(np.ones((3, 100), np.float32)), rtol=0, atol=1e-6)
+    rec2.graph.close()
+    for d in (d_a, d_b):
+        d.close()
+    cx2.close()
+    chain()
+    assert np.array_equal(d_img.numpy(), got)                 # (the context of the first recording still works)
+
+
+def test_us_render_replays_its_chain_from_the_third_call_on(mi):
+    """us_render on one scene with one set of arguments (the loop of USMain.py:262-289): call 1 queues the chain, call 2 queues and
+    records it, calls 3.. replay the recording -- same image as the plain path at the acquisition's tolerance (f32 atomics), a
+    material update between two replays is seen, other arguments fall back to the plain path, a context that profiles never
+    replays."""
+    sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=16, seed=5)
+    ui = sc.integrator()
+    kw = dict(x_range=(-0.012, 0.012), z_range=(0.03, 0.07), return_bmode=True)
+    imgs, flags = [], []
+    for i in range(5):
+        tm = {}
+        d, b, _ = mi.us_render(sc, timing=tm, **kw)
+        imgs.append(b)
+        flags.append(tm["replayed"])
+    assert flags == [False, False, True, True, True]
+    st = sc.device().ctx.stats()                                               # of the last replay
+    assert st["kernel_ms"] == 0.0 and st["samples"] == 5 * 64 * 16 and ui.ray_count == st["segments"] > 0   # (no event pairs in a replay)
+    assert ui.transmission_delays_buf.shape == (5 * 64,)
+    plain = mi.us_render(sc, graph=False, **kw)[1]
+    assert sc.device().ctx.stats()["kernel_ms"] > 0.0
+    for b in imgs:
+        assert np.allclose(b, plain, rtol=0, atol=2e-5 * plain.max())
+    # the finite-difference step: roughness changes in device memory, the replay sees it
+    params = mi.traverse(sc)
+    key = [k for k in params.keys() if k.endswith("flat_plate.bsdf.roughness")][0]
+    params[key] = 0.3
+    params.update()
+    tm = {}
+    rough = mi.us_render(sc, timing=tm, **kw)[1]
+    assert tm["replayed"]
+    rough_plain = mi.us_render(sc, graph=False, **kw)[1]
+    assert np.allclose(rough, rough_plain, rtol=0, atol=2e-5 * rough_plain.max())
+    assert not np.allclose(rough, plain, rtol=0, atol=1e-3 * plain.max())
+    # another seed is another key: plain path, then its own recording
+    tm = {}
+    mi.us_render(sc, seed=77, timing=tm, **kw)
+    assert not tm["replayed"]
+    cx = sc.device().ctx
+    cx.set_profiling(True)
+    tm = {}
+    mi.us_render(sc, timing=tm, **kw)
+    das_ms = cx.image_stats()["das_ms"]
+    cx.set_profiling(False)
+    assert not tm["replayed"] and das_ms > 0

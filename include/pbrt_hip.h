@@ -553,8 +553,9 @@ int pbrt_get_image_stats(pbrt_ctx *ctx, pbrt_image_stats *out);
  *    READ through those pointers is not: pbrt_scene_update_material between two launches is seen by the second one (the
  *    finite-difference loop of USMain.py:262-289 changes one roughness per render and nothing else).
  *  - The workspace must be warm: run the chain once the ordinary way first; a recorded call that would have to allocate, or to
- *    upload a table, fails with PBRT_E_INVALID.  Any other entry point on the context fails with PBRT_E_INVALID while a
- *    recording is open.  An error inside a recording leaves it open: close it with pbrt_ctx_record_end (which then reports it).
+ *    upload a table, fails (PBRT_E_NOMEM / PBRT_E_INVALID; the message names the buffer or table).  An error of a recorded
+ *    call leaves the recording open: close it with pbrt_ctx_record_end, which reports the error again and makes no graph.
+ *    Any other entry point on the context is refused with PBRT_E_INVALID while a recording is open (the recording stays good).
  *  - A recording goes stale when the context frees or replaces memory it refers to (a larger request for the same workspace
  *    buffer, pbrt_ctx_trim, pbrt_dev_free, pbrt_scene_destroy) or uploads other acquisition tables: pbrt_graph_launch then
  *    returns PBRT_E_INVALID and launches nothing; record again. */
@@ -562,6 +563,7 @@ typedef struct pbrt_graph pbrt_graph;
 int pbrt_ctx_record_begin(pbrt_ctx *ctx);
 int pbrt_ctx_record_end(pbrt_ctx *ctx, pbrt_graph **out);
 int pbrt_graph_launch(pbrt_graph *g);
+/* waits for the context's stream (a replay may still run).  Destroy a context's recordings before the context. */
 int pbrt_graph_destroy(pbrt_graph *g);
 
 #ifdef __cplusplus

@@ -90,7 +90,8 @@ struct pbrt_ctx {
     // open the context's stream captures instead of running, nothing may wait for it, allocate or upload.  ws_epoch counts the
     // events that make a finished recording stale: memory it may refer to freed or replaced, other acquisition tables uploaded,
     // the envelope's tap table made for another column length.
-    bool recording = false;
+    bool recording = false, rec_failed = false;
+    std::string rec_msg;
     uint64_t ws_epoch = 0;
     uint32_t n_graphs = 0;
 
@@ -101,7 +102,16 @@ struct pbrt_ctx {
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
         err = buf;
+        if (recording && !rec_failed) {  // the first error inside a recording: pbrt_ctx_record_end reports it again and makes no graph
+            rec_failed = true;
+            rec_msg = buf;
+        }
         return code;
+    }
+    // an entry point that may not run while the stream records: the same, but the recording stays good
+    int refuse(const char *what) {
+        err = std::string("a recording is open on this context (pbrt_ctx_record_begin): ") + what;
+        return PBRT_E_INVALID;
     }
     // returns nullptr on failure (err set)
     void *buf(const char *name, size_t bytes) {
@@ -190,8 +200,7 @@ struct pbrt_scene {
 // entry points that wait, copy from host memory or free: not while the context's stream records (pbrt_ctx_record_begin)
 #define NOT_RECORDING(ctx)                                                                                                   \
     do {                                                                                                                     \
-        if ((ctx)->recording)                                                                                                \
-            return (ctx)->fail(PBRT_E_INVALID, "a recording is open on this context (pbrt_ctx_record_begin): %s cannot run", __func__); \
+        if ((ctx)->recording) return (ctx)->refuse((std::string(__func__) + " cannot run").c_str());                         \
     } while (0)
 
 // finishes an acquisition that was queued without waiting (pbrt_us_acquire_queue_dev): waits for the stream, checks the guard words,
@@ -200,7 +209,7 @@ static int us_finish(pbrt_ctx *c);
 static inline int ctx_settle(pbrt_ctx *c) {
     // (every entry point that waits for the stream or starts work of its own comes through here: none of them may run while the
     // stream records -- a wait would invalidate the capture)
-    if (c->recording) return c->fail(PBRT_E_INVALID, "a recording is open on this context (pbrt_ctx_record_begin): only the queueing entry points may be called");
+    if (c->recording) return c->refuse("only the queueing entry points may be called");
     return c->pend.active ? us_finish(c) : PBRT_OK;
 }
 
@@ -374,6 +383,13 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
 int pbrt_ctx_destroy(pbrt_ctx *c) {
     if (!c) return PBRT_OK;
     (void)hipSetDevice(c->device);
+    if (c->recording) {  // an open recording: close the capture and drop it
+        hipGraph_t g = nullptr;
+        if (hipStreamEndCapture(c->stream, &g) == hipSuccess && g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        c->recording = false;
+        c->pend.active = false;
+    }
     (void)ctx_settle(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->st_trace) (void)hipStreamSynchronize(c->st_trace);
@@ -2782,6 +2798,8 @@ int pbrt_ctx_record_begin(pbrt_ctx *c) {
     // relaxed: the recorded entry points query function attributes and free memory, calls a stricter mode refuses on any thread
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeRelaxed));
     c->recording = true;
+    c->rec_failed = false;
+    c->rec_msg.clear();
     return PBRT_OK;
 }
 
@@ -2797,6 +2815,10 @@ int pbrt_ctx_record_end(pbrt_ctx *c, pbrt_graph **out) {
     if (e != hipSuccess || !g) {
         (void)hipGetLastError();
         return c->fail(PBRT_E_DEVICE, "hipStreamEndCapture: %s (a call inside the recording failed or waited)", hipGetErrorString(e));
+    }
+    if (c->rec_failed) {  // (the capture itself is intact, but what it holds is not the chain the caller meant)
+        (void)hipGraphDestroy(g);
+        return c->fail(PBRT_E_INVALID, "a call inside the recording failed: %s", c->rec_msg.c_str());
     }
     hipGraphExec_t x = nullptr;
     e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);

@@ -330,6 +330,12 @@ def test_recorded_chain_replays_the_queued_calls(mi, capi):
     # a recording that would have to allocate fails inside (a fresh context: no tap table yet), and the context works afterwards
     cx2 = capi.Context(cx.device)
     d_a, d_b = mi.DeviceBuffer.from_host(cx2, np.ones((3, 100), np.float32)), mi.DeviceBuffer(cx2, (3, 100))
+    import ctypes as C
+    h = capi._P()
+    assert cx2.lib.pbrt_ctx_record_begin(cx2.handle) == 0
+    assert cx2.lib.pbrt_envelope_dev(cx2.handle, 3, 100, capi._P(d_a.ptr), capi._P(d_b.ptr)) != 0
+    assert cx2.lib.pbrt_ctx_record_end(cx2.handle, C.byref(h)) != 0 and not h.value     # reported again, no graph made
+    assert b"inside the recording failed" in cx2.lib.pbrt_last_error(cx2.handle)
     with pytest.raises(RuntimeError, match="run the chain once"):
         with cx2.record():
             mi.envelope(d_a, out=d_b)

@@ -302,11 +302,11 @@ __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params
 // the tap table of a column length N, g[C + k] = h[k] for 0 < k < N, -h[-k] for -N < k < 0, 0 elsewhere (C = Np + 4, 2 Np + 8 entries):
 // computed once per N and kept by the context -- every column of every image of a loop uses the same one, and the f64 sincospi and
 // division per tap were most of the kernel when each workgroup made its own copy (47 -> 2x us at 1040 columns of 638)
-__global__ __launch_bounds__(256) void k_hilbert_taps(uint32_t N, float *__restrict__ g) {
-    const uint32_t Np = (N + 3u) & ~3u, C = Np + 4u, G = 2u * Np + 8u;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= G) return;
-    const int32_t k = (int32_t)j - (int32_t)C;
+// (even N: followed, at ENV_TAPS_EVEN floats from the start, by the four compact tables of k_hilbert_env_even in the layout of its LDS)
+#define ENV_TAPS_EVEN (2u * ENV_MAX_N + 8u)
+__host__ DEV uint32_t env_even_len(uint32_t Mp) { return 2u * Mp + 16u; }  // entries of one compact table of k_hilbert_env_even
+#define ENV_TAPS_FLOATS (ENV_TAPS_EVEN + 4u * (ENV_MAX_N + 16u))
+DEV float hilbert_tap(uint32_t N, int32_t k) {  // h[k] for 0 < |k| < N (odd symmetry), 0 elsewhere
     const uint32_t n = (uint32_t)(k < 0 ? -k : k);
     double h = 0.0;
     if (n >= 1u && n < N) {
@@ -320,7 +320,22 @@ __global__ __launch_bounds__(256) void k_hilbert_taps(uint32_t N, float *__restr
             h = (n & 1u) ? inv_n * cs / sn : -inv_n * sn / cs;
         }
     }
-    g[j] = (float)(k < 0 ? -h : h);
+    return (float)(k < 0 ? -h : h);
+}
+__global__ __launch_bounds__(256) void k_hilbert_taps(uint32_t N, float *__restrict__ g) {
+    const uint32_t Np = (N + 3u) & ~3u, C = Np + 4u, G = 2u * Np + 8u;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < G) {
+        g[j] = hilbert_tap(N, (int32_t)j - (int32_t)C);
+        return;
+    }
+    if (N & 1u) return;
+    // table t of k_hilbert_env_even, entry i: e = i - origin (tables 0, 2: Mp + 3; 1, 3: Mp + 1); tables 0, 1: U0[e] = h[2 e - 1], 2, 3: U1[e] = h[2 e + 1]
+    const uint32_t Mp = ((N >> 1) + 3u) & ~3u, L = env_even_len(Mp), jj = j - G;
+    if (jj >= 4u * L) return;
+    const uint32_t t = jj / L, i = jj - t * L;
+    const int32_t e = (int32_t)i - (int32_t)(Mp + ((t & 1u) ? 1u : 3u));
+    g[ENV_TAPS_EVEN + jj] = hilbert_tap(N, 2 * e + ((t & 2u) ? 1 : -1));
 }
 __global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *__restrict__ rf, const float *__restrict__ taps,
                                                      float *__restrict__ env) {
@@ -329,8 +344,21 @@ __global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *_
     float *xs = lds_env;      // [Np], zero beyond N (the tail of the column, and the outputs' own samples)
     float *g = lds_env + Np;  // the tap table
     const float *xr = rf + (size_t)col * N;
-    for (uint32_t j = threadIdx.x; j < Np; j += blockDim.x) xs[j] = j < N ? xr[j] : 0.0f;
-    for (uint32_t j = threadIdx.x; j < G; j += blockDim.x) g[j] = taps[j];
+    // (four loads in flight per thread and round: one at a time, this copy is a chain of L2 round trips)
+    for (uint32_t j0 = threadIdx.x; j0 < G; j0 += 4u * blockDim.x) {
+        float v[4], w[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            v[u] = taps[min(j0 + u * blockDim.x, G - 1u)];
+            w[u] = xr[min(j0 + u * blockDim.x, N - 1u)];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t j = j0 + u * blockDim.x;
+            if (j < G) g[j] = v[u];
+            if (j < Np) xs[j] = j < N ? w[u] : 0.0f;
+        }
+    }
     __syncthreads();
     // The kernel is bound by LDS reads, not by its multiply-adds: three 16-byte reads per 16 of them (the four samples as a broadcast,
     // the tap window as two quads) kept the LDS of a CU busy for 3 x as long as its SIMDs.  The window of trip m + 4 starts four taps
@@ -359,6 +387,94 @@ __global__ __launch_bounds__(256) void k_hilbert_env(uint32_t nz, const float *_
         if (m < Np) ENV_TRIP(xs[m], xs[m + 1u], xs[m + 2u], xs[m + 3u])  // the last, partial quad: zero-padded copy in LDS
 #undef ENV_TRIP
         const float xh[4] = {a0, a1, a2, a3};
+        for (uint32_t j = 0; j < 4u; ++j)
+            if (n0 + j < N) env[(size_t)col * N + n0 + j] = sqrtf(fma_(xs[n0 + j], xs[n0 + j], xh[j] * xh[j]));
+    }
+}
+
+// Even column lengths (round 5, second half).  For even N every even tap is exactly zero (h[n] = (2 / N) cot(pi n / N) for odd n only):
+// an even output sample is a sum over the ODD input samples and the other way round, and half of the N^2 multiply-adds above multiply
+// by 0.  k_hilbert_env_even leaves them out: the column splits into its even and odd samples (p <-> n = 2 p + s), an output p of
+// parity s meets the inputs q of the other parity with the tap h[2 (p - q) + 2 s - 1], i.e. two circular convolutions of half the
+// length over ONE compact table U[e] = h[2 e + 1] (odd outputs read U[p - q], even outputs U[p - q - 1]).  A thread carries four
+// consecutive outputs (two of each parity) over eight consecutive inputs per trip -- all eight are used, so they stay wave-uniform
+// scalar loads -- and reads one tap quad per parity and trip; the two tables are kept at two alignments each so that the quad of
+// a thread with p0 = 2 (mod 4) is a 16-byte read as well.  Same sums in the same order as k_hilbert_env (a product with a zero tap
+// leaves the accumulator unchanged), so the same bits for finite input.  1040 columns of 638: 27.5 -> 20 us, not the 14 the
+// multiply-adds promise: a column is 160 quads = two and a half waves, so a sixth of the lanes idle, and a wave issues its 1 280
+// multiply-adds in 80 trips that each wait for their loads with three waves per SIMD to cover them (SQ counters: VALU issue 35 %
+// busy, 38 % of a wave's life in s_waitcnt).  Tried on top, both flat: the loads of trip q + 1 requested before the
+// multiply-adds of trip q (two register sets taking turns: 20.6 us, the copies cost what the waits gave), the copies of a table
+// 32 banks apart instead of 16 (20.8 us; the counters show 4 % of the LDS cycles in bank conflicts).
+// LDS: column [2 Mp] + four tables [2 Mp + 16], M = N / 2, Mp = M rounded up to 4.
+__global__ __launch_bounds__(256) void k_hilbert_env_even(uint32_t nz, const float *__restrict__ rf, const float *__restrict__ taps,
+                                                          float *__restrict__ env) {
+    extern __shared__ __attribute__((aligned(16))) float lds_env[];
+    const uint32_t N = nz, col = blockIdx.x;
+    const uint32_t M = N >> 1, Mp = (M + 3u) & ~3u, L = env_even_len(Mp);
+    float *xs = lds_env;              // [2 Mp], zero beyond N
+    float *tab = lds_env + 2u * Mp;   // [4][L]: U0 (even outputs) at origin Mp + 3 / Mp + 1, U1 (odd outputs) at origin Mp + 3 / Mp + 1
+    const float *xr = rf + (size_t)col * N;
+    // the column and the four tables (made once by k_hilbert_taps, in this layout) into LDS: four 16-byte loads in flight per thread
+    // and round -- one load per round made this copy a chain of 17 L2 round trips, half of the kernel's time
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(taps + ENV_TAPS_EVEN);
+        float4 *dst = reinterpret_cast<float4 *>(tab);
+        const uint32_t n4 = L;  // 4 L floats
+        for (uint32_t j0 = threadIdx.x; j0 < n4; j0 += 4u * blockDim.x) {
+            float4 v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) v[u] = src[min(j0 + u * blockDim.x, n4 - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                if (j0 + u * blockDim.x < n4) dst[j0 + u * blockDim.x] = v[u];
+        }
+        for (uint32_t j0 = threadIdx.x; j0 < 2u * Mp; j0 += 4u * blockDim.x) {
+            float v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) v[u] = xr[min(j0 + u * blockDim.x, N - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                if (j0 + u * blockDim.x < 2u * Mp) xs[j0 + u * blockDim.x] = j0 + u * blockDim.x < N ? v[u] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const uint32_t items = (N + 3u) >> 2;
+    for (uint32_t it = threadIdx.x; it < items; it += blockDim.x) {
+        const uint32_t p0 = 2u * it;   // outputs n = 4 it + (0, 1, 2, 3) = even p0, odd p0, even p0 + 1, odd p0 + 1
+        const uint32_t O = Mp + ((it & 1u) ? 1u : 3u);
+        const float *u0 = tab + ((it & 1u) ? L : 0u) + O + p0;        // u0[e - p0] = U0[e]
+        const float *u1 = tab + ((it & 1u) ? 3u * L : 2u * L) + O + p0;
+        float e0 = 0.0f, e1 = 0.0f, o0 = 0.0f, o1 = 0.0f;
+        float pe = u0[1], po = u1[1];  // tap (p0 - q) + 1 of either table: the lowest tap of the trip before
+#define ENV_TRIP2(x0, x1, x2, x3, x4, x5, x6, x7, c0, c1)                                                      \
+    {                                                                                                          \
+        /* output p0 + j, input q + i: tap (p0 - q) + j - i = window index 3 + j - i of (c.x, c.y, c.z, c.w, p) */ \
+        e0 = fma_(x1, c0.w, e0); e0 = fma_(x3, c0.z, e0); e0 = fma_(x5, c0.y, e0); e0 = fma_(x7, c0.x, e0);    \
+        o0 = fma_(x0, c1.w, o0); o0 = fma_(x2, c1.z, o0); o0 = fma_(x4, c1.y, o0); o0 = fma_(x6, c1.x, o0);    \
+        e1 = fma_(x1, pe, e1);   e1 = fma_(x3, c0.w, e1); e1 = fma_(x5, c0.z, e1); e1 = fma_(x7, c0.y, e1);    \
+        o1 = fma_(x0, po, o1);   o1 = fma_(x2, c1.w, o1); o1 = fma_(x4, c1.z, o1); o1 = fma_(x6, c1.y, o1);    \
+        pe = c0.x;                                                                                             \
+        po = c1.x;                                                                                             \
+    }
+#define ENV_WIN(t, qq) (*reinterpret_cast<const float4 *>((t) - (int32_t)(qq) - 3))
+        uint32_t q = 0;
+        const uint32_t full = M & ~3u;  // trips whose eight samples lie inside the column: scalar loads, two trips per wait
+#pragma unroll 2
+        for (; q < full; q += 4u) {
+            const float *x = xr + 2u * q;
+            const float4 w0 = ENV_WIN(u0, q), w1 = ENV_WIN(u1, q);
+            ENV_TRIP2(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], w0, w1)
+        }
+        if (q < Mp) {
+            const float *x = xs + 2u * q;
+            const float4 w0 = ENV_WIN(u0, q), w1 = ENV_WIN(u1, q);
+            ENV_TRIP2(x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7], w0, w1)
+        }
+#undef ENV_WIN
+#undef ENV_TRIP2
+        const float xh[4] = {e0, o0, e1, o1};
+        const uint32_t n0 = 4u * it;
         for (uint32_t j = 0; j < 4u; ++j)
             if (n0 + j < N) env[(size_t)col * N + n0 + j] = sqrtf(fma_(xs[n0 + j], xs[n0 + j], xh[j] * xh[j]));
     }

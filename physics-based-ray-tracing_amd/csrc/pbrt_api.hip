@@ -2524,20 +2524,31 @@ static int env_enqueue(pbrt_ctx *c, uint32_t nx, uint32_t nz, const float *din, 
     const uint32_t np = (nz + 3u) & ~3u, G = 2u * np + 8u;
     // the tap table of this column length: made once, kept while the workspace buffer lives (pbrt_ctx_trim may take it)
     const bool fresh = c->ws.find("env_taps") == c->ws.end() || c->ws["env_taps"].p == nullptr;
-    float *taps = (float *)c->buf("env_taps", (size_t)(2u * ENV_MAX_N + 8u) * 4);
+    float *taps = (float *)c->buf("env_taps", (size_t)ENV_TAPS_FLOATS * 4);
     if (!taps) return PBRT_E_NOMEM;
     ImgTimer tm(c, IMG_ENV);
     if (fresh || c->env_taps_n != nz) {
         ++c->ws_epoch;  // (a finished recording holds no launch of this kernel: its taps are replaced now)
-        hipLaunchKernelGGL(k_hilbert_taps, dim3(div_up(G, 256)), dim3(256), 0, c->stream, nz, taps);
+        hipLaunchKernelGGL(k_hilbert_taps, dim3(div_up(G + 4u * env_even_len(((nz >> 1) + 3u) & ~3u), 256)), dim3(256), 0, c->stream, nz, taps);
         c->env_taps_n = nz;
     }
-    const size_t lds = (size_t)(3u * np + 8u) * 4;
+    // even column lengths: half of the taps are zero, k_hilbert_env_even leaves their multiply-adds out (kernels_beamform.h)
+    const uint32_t mp = ((nz >> 1) + 3u) & ~3u;
+    const size_t lds_even = (size_t)(2u * mp + 4u * env_even_len(mp)) * 4;  // (its four tap tables: 3.3 x the column; 80 KB at 4096 samples)
+    const char *e_gen = getenv("PBRT_ENV_GENERAL");  // A/B and test: every column length through k_hilbert_env (read per call)
+    const bool even = (nz & 1u) == 0u && nz >= 8u && lds_even <= (c->lds_limit ? c->lds_limit : 65536u) && !(e_gen && atoi(e_gen) != 0);
+    const size_t lds = even ? lds_even : (size_t)(3u * np + 8u) * 4;
     if (lds > c->env_lds_attr) {
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hilbert_env_even), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         c->env_lds_attr = lds;
     }
-    hipLaunchKernelGGL(k_hilbert_env, dim3(nx), dim3(256), lds, c->stream, nz, din, taps, dout);
+    // a thread carries four outputs: whole waves for the quads of a column (638 samples: 160 quads, three waves)
+    const uint32_t threads = std::min(256u, div_up(div_up(nz, 4u), 64u) * 64u);
+    if (even)
+        hipLaunchKernelGGL(k_hilbert_env_even, dim3(nx), dim3(threads), lds, c->stream, nz, din, taps, dout);
+    else
+        hipLaunchKernelGGL(k_hilbert_env, dim3(nx), dim3(threads), lds, c->stream, nz, din, taps, dout);
     HIPCHK(c, hipGetLastError());
     return PBRT_OK;
 }

@@ -249,6 +249,22 @@ def test_envelope_of_odd_and_even_columns_against_scipy_definition(mi):
         assert np.allclose(got, ref, rtol=0, atol=2e-4 * max(ref.max(), 1e-6)), N
 
 
+def test_even_columns_skip_the_zero_taps_and_change_no_bit(mi, monkeypatch):
+    """k_hilbert_env_even (even column lengths: every even tap of the discrete Hilbert kernel is zero, so an even output is a sum over
+    the odd inputs only) against k_hilbert_env on the same columns: the same sums in the same order, bit for bit"""
+    for N in (8, 10, 12, 14, 30, 256, 638, 1000, 4094, 4096):
+        rng = np.random.default_rng(500 + N)
+        rf = rng.normal(size=(5, N)).astype(np.float32)
+        rf[1] = 0.0
+        rf[2, N // 3] = 1e6                                 # (a spike: every output of the column sees one tap of it)
+        got = mi.envelope(rf)
+        monkeypatch.setenv("PBRT_ENV_GENERAL", "1")
+        ref = mi.envelope(rf)
+        monkeypatch.delenv("PBRT_ENV_GENERAL")
+        assert np.array_equal(got, ref), N
+        assert np.allclose(got, obf.envelope(rf), rtol=0, atol=2e-4 * np.abs(rf).max()), N
+
+
 def test_a_queued_acquisition_reports_with_the_next_waiting_call(mi, capi):
     """pbrt_us_acquire_queue_dev (ABI 5): the call returns with the acquisition queued; the channel buffer is complete for the kernels
     queued behind it and for the host after a download; statistics (and a tripped guard) arrive with the next call that waits."""

@@ -90,6 +90,9 @@ DEV double das_dist(double r) {
 // (v_fract / v_floor) -- 2-cycle instructions -- where the f64 form needs add, multiply, floor / convert, subtract, convert at 4
 // cycles each per (element, angle).  The fraction keeps 24 bits (1.2e-7 samples; the f64 form rounds the interpolation weight
 // to f32 as well), the whole part is exact.
+#ifndef DAS_PAIR
+#define DAS_PAIR 0   // A/B (round 5): linear interpolation with two elements per trip of a wave, their gathers in flight together.  Same
+#endif               // bits, 74.6 -> 107.5 us: 81 VGPRs (5 waves per SIMD instead of 7) and every lane loads (profiles/r05_das_variants.txt)
 struct DasPos {
     int32_t i;
     float f;
@@ -239,7 +242,54 @@ __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params
         for (uint32_t eb = 0; eb < E; eb += 64u) {
             const uint32_t ne = min(64u, E - eb);
             const double ex_l = (double)elem_x[eb + min(lane, ne - 1u)];
+#if DAS_PAIR
+            // Linear interpolation, TWO elements of this wave's share per trip: the 4 x DAS_ANG samples of both are requested before
+            // the first is used (one element per trip leaves a wave waiting for its ten gathers 63 % of its life: SQ_WAIT_ANY /
+            // SQ_WAVE_CYCLES at five resident waves per SIMD).  Same sums in the same order, same bits -- and slower: see DAS_PAIR.
+            for (uint32_t el = wave; INTERP == PBRT_DAS_LINEAR && el < ne; el += 2u * DAS_SPLIT) {
+                float v0[2][DAS_ANG], v1[2][DAS_ANG], ww[2][DAS_ANG];
+                uint32_t kind[2] = {0u, 0u};  // per angle two bits: 1 interpolate, 2 exactly the last sample
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; ++u) {
+                    const uint32_t elu = el + u * DAS_SPLIT;
+                    const bool have = elu < ne;  // (wave-uniform)
+                    const uint32_t e = eb + min(elu, ne - 1u);
+                    const double dx = x - das_lane_f64(ex_l, min(elu, ne - 1u));
+                    const bool in_ap = have && any && fabs(dx) <= half_ap;
+#pragma unroll
+                    for (uint32_t j = 0; j < DAS_ANG; ++j) v0[u][j] = v1[u][j] = ww[u][j] = 0.0f;
+                    if (__ballot(in_ap) == 0ull) continue;
+                    const DasPos dp = das_split(das_dist(dx * dx + zz) * inv_c * fs);
+#pragma unroll
+                    for (uint32_t j = 0; j < DAS_ANG; ++j) {
+                        if (j >= na) break;
+                        const float *trace = data + ((size_t)(a0 + j) * E + e) * T;
+                        const float fr = tp[j].f + dp.f;  // [0, 2)
+                        const float fl = floorf(fr);
+                        const float w = fr - fl;
+                        const uint32_t i0 = (uint32_t)(tp[j].i + dp.i + (int32_t)fl);
+                        const bool ok = in_ap && i0 < T - 1u, lastok = in_ap && i0 == T - 1u && w == 0.0f;
+                        const uint32_t ic = ok ? i0 : (T - 2u);  // (every lane loads: 94 % of the lanes of a trip are in the aperture)
+                        v0[u][j] = trace[ic];
+                        v1[u][j] = trace[ic + 1u];
+                        ww[u][j] = w;
+                        kind[u] |= (ok ? 1u : lastok ? 2u : 0u) << (2u * j);
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 2u; ++u) {
+#pragma unroll
+                    for (uint32_t j = 0; j < DAS_ANG; ++j) {
+                        const uint32_t k = (kind[u] >> (2u * j)) & 3u;
+                        const float val = k == 1u ? fma_(ww[u][j], v1[u][j] - v0[u][j], v0[u][j]) : v1[u][j];  // (k == 2: trace[T - 1])
+                        acc = k ? acc + val : acc;
+                    }
+                }
+            }
+            for (uint32_t el = wave; INTERP != PBRT_DAS_LINEAR && el < ne; el += DAS_SPLIT) {
+#else
             for (uint32_t el = wave; el < ne; el += DAS_SPLIT) {
+#endif
                 const uint32_t e = eb + el;
                 const double dx = x - das_lane_f64(ex_l, el);
                 const bool in_ap = any && fabs(dx) <= half_ap;

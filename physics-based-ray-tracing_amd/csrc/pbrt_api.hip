@@ -62,6 +62,7 @@ struct pbrt_ctx {
     // stream or starts other work on the context finishes it first (ctx_settle).
     struct PendingAcq {
         bool active = false, streams = false, tab0 = false;
+        bool scaled = true;  // the normalisation pass over the channel buffer ran (not at one path per ray)
         bool timed = true;  // false: replayed from a recording (no event pairs; kernel_ms / bounce_ms are 0)
         size_t n_ev = 0;
         uint32_t passes = 0, launches = 0;
@@ -2138,7 +2139,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         if (timed) HIPCHK(c, hipEventRecord(pass_e1, st));
     }
     const float inv_norm = 1.0f / (float)(norm_paths ? norm_paths : 1);
-    hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
+    // (one path per ray, the reference's own setting (USMain.py:36): the factor is exactly 1 and the pass over the buffer changes no bit)
+    if (inv_norm != 1.0f) hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
     HIPCHK(c, hipGetLastError());
     if (timed) HIPCHK(c, hipEventRecord(c->ev1, st));
     hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
@@ -2149,6 +2151,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     pbrt_ctx::PendingAcq &P = c->pend;
     P.active = true;
     P.timed = timed;
+    P.scaled = inv_norm != 1.0f;
     P.streams = streams;
     P.tab0 = a.first_hit != nullptr;
     P.n_ev = n_ev;
@@ -2218,7 +2221,7 @@ static int us_finish(pbrt_ctx *c) {
         S.trace_model_bytes = tr;
     }
     S.bounce_model_bytes = bb;
-    S.model_bytes = bb + P.nchan * 12;  // clear + scale pass over the channel buffer
+    S.model_bytes = bb + P.nchan * (P.scaled ? 12 : 4);  // clear (+ scale pass) over the channel buffer
     S.workspace_bytes = c->ws_total();
     return PBRT_OK;
 }

@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256) void k_das_first_arrival(pbrt_das_params p, co
 // for a scan whose delays and grid do not change -- the 51 renders of USMain.py share one) instead of a pass over all elements
 // per call; the rest of the kernel, and every bit of its result, is the same.
 template <uint32_t INTERP, bool TABLE>
+#ifdef DAS_WAVES_PER_EU  // A/B: register budget of the kernel (default: what the compiler takes, 70 VGPRs = 7 waves per SIMD)
+__attribute__((amdgpu_waves_per_eu(DAS_WAVES_PER_EU, DAS_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(64 * DAS_SPLIT) void k_das_beamform(pbrt_das_params p, DasGrid grid, const float *__restrict__ data,
                                                                  const float *__restrict__ tx, const float *__restrict__ elem_x,
                                                                  const float *__restrict__ gx, const float *__restrict__ gz,

@@ -1195,6 +1195,27 @@ __global__ __launch_bounds__(256) void k_reduce_stats(const unsigned long long *
     if (threadIdx.x == 0 && part[0]) atomicAdd(&out[blockIdx.x], part[0]);
 }
 
+// The ultrasound acquisition's form (round 5): slice s of row r leaves its partial sum in out[r * REDUCE_SLICES + s] -- `out` is the
+// context's pinned host page, written by the kernel itself, the host adds the slices -- and ZEROES the counters it has read, so that
+// the next acquisition finds its rows clean.  No fill command in front of the counters and no copy command behind them: at one path
+// per ray (USMain.py:36) those two were 9 of the 60 us an acquisition kept the device.
+__global__ __launch_bounds__(256) void k_us_reduce_stats(unsigned long long *stats, uint32_t nseg, size_t stride,
+                                                         unsigned long long *out) {
+    __shared__ unsigned long long part[4];
+    unsigned long long *row = stats + (size_t)blockIdx.x * stride;
+    const uint32_t per = (nseg + gridDim.y - 1) / gridDim.y, lo = min(blockIdx.y * per, nseg), hi = min(lo + per, nseg);
+    unsigned long long s = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+        s += row[i];
+        row[i] = 0ull;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = part[0] + part[1] + part[2] + part[3];
+}
+
 // ---- film: deterministic gather of the pass's samples through the reconstruction filter -----------
 struct FilmArgs {
     const float *Lhome;  // [cap] float4 records (r, g, b, 0)

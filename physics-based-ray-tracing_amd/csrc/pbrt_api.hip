@@ -26,6 +26,10 @@ struct DevBuf {
     uint64_t stamp = 0; // pbrt_ctx::call_seq of that request
 };
 
+// the context's pinned host page: partial sums of the ultrasound counters (written by k_us_reduce_stats itself), then the guard words
+#define PIN_GUARD_OFFSET ((2 + MAX_DEPTH_STATS) * REDUCE_SLICES * 8)
+#define PIN_BYTES (PIN_GUARD_OFFSET + 4096)
+
 struct pbrt_ctx {
     int device = 0;
     int n_cu = 256;  // compute units (MI355X: 256); read from the device properties
@@ -71,8 +75,12 @@ struct pbrt_ctx {
     // one page of pinned host memory: the statistics and guard words of a call are copied here (a copy to pageable memory blocks
     // the host until it is done; to pinned memory it is queued like a kernel)
     void *pinned = nullptr;
-    unsigned long long *pin_stats() { return (unsigned long long *)pinned; }              // [2 + 2 * MAX_DEPTH_STATS]
-    uint32_t *pin_guard() { return (uint32_t *)((char *)pinned + 1024); }                  // [WF_GUARD_WORDS]
+    unsigned long long *pin_stats() { return (unsigned long long *)pinned; }              // [2 + MAX_DEPTH_STATS][REDUCE_SLICES] partial sums
+    uint32_t *pin_guard() { return (uint32_t *)((char *)pinned + PIN_GUARD_OFFSET); }      // [WF_GUARD_WORDS]
+    // the ultrasound counters (workspace "us_stats") as the last acquisition left them: k_us_reduce_stats zeroes what it reads, so a
+    // call that finds the same buffer and this flag set skips the fill command
+    const void *us_rows_clean = nullptr;
+    size_t us_rows_clean_bytes = 0;
     // the small tables of the last acquisition (transmit delays, primary directions, element positions) as uploaded: the
     // reference's loop calls the acquisition 51 times with the same ones (USMain.py:260,279-283), three host-to-device copies each
     std::vector<float> us_tab_host;
@@ -364,13 +372,13 @@ int pbrt_ctx_create(int device, pbrt_ctx **out) {
         delete c;
         return PBRT_E_DEVICE;
     }
-    if ((e = hipHostMalloc(&c->pinned, 4096, hipHostMallocDefault)) != hipSuccess) {
+    if ((e = hipHostMalloc(&c->pinned, PIN_BYTES, hipHostMallocDefault)) != hipSuccess) {
         g_ctxless_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
         (void)hipStreamDestroy(c->stream);
         delete c;
         return PBRT_E_NOMEM;
     }
-    std::memset(c->pinned, 0, 4096);
+    std::memset(c->pinned, 0, PIN_BYTES);
     if (const char *lim = getenv("PBRT_WORKSPACE_LIMIT_BYTES")) c->ws_limit = (size_t)strtoull(lim, nullptr, 0);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -2004,12 +2012,11 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         segA = (uint32_t *)c->buf("segA", (size_t)n_own * 4);
         segB = (uint32_t *)c->buf("segB", (size_t)n_own * 4);
     }
-    // the totals (a 512-byte head) and the rows they are reduced from in ONE buffer: one fill command clears both
-    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;  // rows, reduced at the end
-    static_assert((2 + MAX_DEPTH_STATS) * 8 <= 512, "the totals fit the head of the statistics buffer");
-    unsigned long long *dstats = (unsigned long long *)c->buf("us_stats", 512 + segstats_bytes);
+    // the counter rows: summed into the pinned page and zeroed again by k_us_reduce_stats at the end of the call
+    const size_t segstats_bytes = (size_t)(2 + MAX_DEPTH_STATS) * n_own * 8;
+    unsigned long long *dstats = (unsigned long long *)c->buf("us_stats", segstats_bytes);
     if (!dstats) return PBRT_E_NOMEM;
-    unsigned long long *segstats = dstats + 64;
+    unsigned long long *segstats = dstats;
     float *tabs = (float *)c->buf("us_tables", ((size_t)n_rays + 3 * NA + NE) * 4);
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
@@ -2035,7 +2042,13 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     }
     const size_t nchan = (size_t)n_rays * T;
     HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
-    HIPCHK(c, hipMemsetAsync(dstats, 0, 512 + segstats_bytes, st));
+    // (the rows are clean if the last acquisition's reduction has swept exactly this buffer; anything else -- a fresh or resized buffer,
+    // a call that failed half-way -- gets the fill)
+    if (c->us_rows_clean != (const void *)dstats || c->us_rows_clean_bytes != segstats_bytes) {
+        if (c->recording) return c->fail(PBRT_E_INVALID, "recording: the acquisition's counters are not clean yet -- run the chain once before recording it");
+        HIPCHK(c, hipMemsetAsync(dstats, 0, segstats_bytes, st));
+    }
+    c->us_rows_clean = nullptr;
     if (timed) HIPCHK(c, hipEventRecord(c->ev0, st));
     UsArgs a{};
     a.sc = s->ds;
@@ -2143,10 +2156,12 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if (inv_norm != 1.0f) hipLaunchKernelGGL(k_scale, dim3(div_up(nchan, 256)), dim3(256), 0, st, d_channel, nchan, inv_norm);
     HIPCHK(c, hipGetLastError());
     if (timed) HIPCHK(c, hipEventRecord(c->ev1, st));
-    hipLaunchKernelGGL(k_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, dstats);
+    // counters into the context's pinned page (partial sums, written by the kernel; the rows are zero again behind it), guard words by
+    // a queued copy; both are read by us_finish once the stream has drained
+    hipLaunchKernelGGL(k_us_reduce_stats, dim3(2 + MAX_DEPTH_STATS, REDUCE_SLICES), dim3(256), 0, st, segstats, n_own, (size_t)n_own, c->pin_stats());
     HIPCHK(c, hipGetLastError());
-    // counters and guard words into the context's pinned page (queued copies), read by us_finish once the stream has drained
-    HIPCHK(c, hipMemcpyAsync(c->pin_stats(), dstats, (2 + MAX_DEPTH_STATS) * 8, hipMemcpyDeviceToHost, st));
+    c->us_rows_clean = dstats;
+    c->us_rows_clean_bytes = segstats_bytes;
     if (streams && (rc = wf_guard_fetch(c, c->pin_guard())) != 0) return rc;
     pbrt_ctx::PendingAcq &P = c->pend;
     P.active = true;
@@ -2172,7 +2187,12 @@ static int us_finish(pbrt_ctx *c) {
     HIPCHK(c, hipStreamSynchronize(st));
     int rc;
     if (P.streams && (rc = wf_check_guard(c, c->pin_guard())) != 0) return rc;
-    const unsigned long long *hstats = c->pin_stats();
+    unsigned long long hstats[2 + MAX_DEPTH_STATS];  // the slices of a row, added here
+    for (uint32_t r = 0; r < 2 + MAX_DEPTH_STATS; ++r) {
+        unsigned long long t = 0;
+        for (uint32_t sl = 0; sl < REDUCE_SLICES; ++sl) t += c->pin_stats()[(size_t)r * REDUCE_SLICES + sl];
+        hstats[r] = t;
+    }
     float ms = 0.0f;
     if (P.timed) HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
     double bounce_ms = 0.0;
@@ -2803,6 +2823,8 @@ struct pbrt_graph {
     pbrt_ctx::PendingAcq pend;  // what the recorded acquisition leaves for us_finish (inactive: the recording holds none)
     uint64_t epoch = 0;         // ctx->ws_epoch at the end of the recording
     uint64_t das_bytes = 0;
+    const void *rows = nullptr; // the counter rows the recorded acquisition expects clean (it was recorded without their fill command)
+    size_t rows_bytes = 0;
 };
 
 int pbrt_ctx_record_begin(pbrt_ctx *c) {
@@ -2849,6 +2871,10 @@ int pbrt_ctx_record_end(pbrt_ctx *c, pbrt_graph **out) {
     G->pend.timed = false;
     G->epoch = c->ws_epoch;
     G->das_bytes = c->img_das_bytes;
+    if (P.active) {
+        G->rows = c->us_rows_clean;
+        G->rows_bytes = c->us_rows_clean_bytes;
+    }
     ++c->n_graphs;
     *out = G;
     return PBRT_OK;
@@ -2860,6 +2886,8 @@ int pbrt_graph_launch(pbrt_graph *G) {
     if (int rc = ctx_settle(c)) return rc;
     if (G->epoch != c->ws_epoch)
         return c->fail(PBRT_E_INVALID, "the recording is stale: memory or tables it refers to were freed or replaced since it was made; record again");
+    if (G->pend.active && (c->us_rows_clean != G->rows || c->us_rows_clean_bytes != G->rows_bytes))
+        return c->fail(PBRT_E_INVALID, "the recording is stale: another acquisition (or one that failed) used the counters since it was made; record again");
     HIPCHK(c, hipSetDevice(c->device));
     ++c->call_seq;
     for (auto &kv : c->ws) kv.second.stamp = c->call_seq;  // (a trim between launches must not take what the replay uses)

@@ -576,13 +576,25 @@ def measure_usmain_loop(env, cfg, steps, warmup, with_cpu):
     first = sizes[0]
     das_ms = first["device_ms_per_render"]["das"]
     achieved = first["das_gbs"] or 0.0
+    # HBM bytes of one k_das_beamform launch from the PMC passes over THIS command (tools/profile_bench.sh r05_usmain --config usmain_loop),
+    # if they were recorded on these kernel sources
+    das_traffic, das_traffic_source = None, "not measured by this run (HBM bytes need separate rocprofv3 --pmc passes)"
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("usmain_loop")
+        if rec and rec.get("kernel_source_sha16") == kernel_source_hash():
+            das_traffic = rec.get("hbm_bytes_per_launch")
+            das_traffic_source = f"profiles/pmc_traffic.json[usmain_loop] recorded on these kernel sources: {rec.get('how', '')}"
+        elif rec:
+            das_traffic_source += f"; profiles/pmc_traffic.json[usmain_loop] is for sources {rec.get('kernel_source_sha16')}"
+    except Exception:
+        pass
     out = {"metric": cfg["metric"], "value": first["ms_per_iteration"], "unit": "ms", "n_gpus": 1, "steps": steps, "warmup": warmup,
            "ms_per_step": first["ms_per_iteration"], "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (sample positions f64)",
            "data": "synthetic",
            "config": {"workload": f"{cfg['scene']} ({cfg['what']}); one step = forward(rough) + forward(rough + 1e-3), image {first['image'][1]} x {first['image'][0]} pixels; "
                                   "replicas only (a serial optimisation loop)", "paths_per_ray": list(cfg["ppr"])},
            "roofline": {"bound": "hbm", "kernel": "k_das_beamform", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": das_traffic, "traffic_source": das_traffic_source,
                         "algorithmic_bytes_per_launch": first["das_model_bytes"], "avg_launch_ms": das_ms,
                         "note": "algorithmic bytes = the channel buffer once + the image once; the kernel gathers 2 x n_angles x |aperture| samples per pixel "
                                 "from L2 at f64 sample positions: it runs against the texture / L2 gather rate and f64 issue, not HBM"},

@@ -30,6 +30,9 @@ families = (kernel, kernel + "_pool")
 if config == "testring":
     families = ("k_trace_primary", "k_trace", "k_shade")
     kernel = "k_trace_primary + k_trace + k_shade"
+if config == "usmain_loop":   # the reference's us_render loop: the roofline kernel of that line is the beamformer
+    families = ("k_das_beamform",)
+    kernel = "k_das_beamform"
 if config == "us_testring":
     families = ("k_trace", "k_us_shade")
     kernel = "k_trace + k_us_shade"

@@ -251,7 +251,7 @@ class _RenderPlan:
         self.d_img = _capi.DeviceBuffer(cx, (nx, nz))
         self.d_table = _capi.DeviceBuffer(cx, (A, nx, nz), np.float64)   # first-arrival times of this scan (das_first_arrival)
         # the queued chain of one key as a recording (pbrt_graph), made at the second call in a row with that key
-        self.graph = self.graph_key = self.warm_key = None
+        self.graph = self.graph_key = self.warm_key = self.no_graph_key = None
 
 
 def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range=60.0, step=None, seed=None,
@@ -356,7 +356,7 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
             das_first_arrival(plan.d_tx, plan.d_ex, plan.d_x, plan.d_z, integ.sound_speed, out=plan.d_table)
             plan.graph = plan.graph_key = plan.warm_key = None
         queue_image_formation()
-        if gkey is not None and plan.warm_key == gkey:
+        if gkey is not None and plan.warm_key == gkey and plan.no_graph_key != gkey:
             # the second call in a row with this key: the workspace is warm, record the chain for the calls that follow
             try:
                 with cx.record() as rec:
@@ -364,7 +364,10 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
                     queue_image_formation()
                 plan.graph, plan.graph_key = rec.graph, gkey
             except RuntimeError:
+                # (a chain that cannot be recorded -- e.g. a pass whose size follows the free device memory of the moment -- is
+                # queued call by call from now on, not tried again at every call)
                 plan.graph = plan.graph_key = None
+                plan.no_graph_key = gkey
         plan.warm_key = gkey
     integ._set_device_channel(rf)
     d_env, d_img = plan.d_env, plan.d_img

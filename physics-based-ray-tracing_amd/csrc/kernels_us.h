@@ -133,8 +133,21 @@ DEV float us_emitter_primary(const pbrt_us_params &p, const float *M, uint32_t r
 // 13.2 / 13.2 / 11.9 / 14.4 ms at 4 / 5 / 6 / 8 waves (8: 30 spilled).
 #define US_N_STATE 11  // origin, direction, amp, atten, tof, geo_len, home
 DEV uint32_t us_state_voff(uint32_t slot, uint32_t rows = US_N_STATE) { return (slot >> 6) * (64u * rows * 4u) + (slot & 63u) * 4u; }
-#define US_AGG_LOG2 8
+// bins of a workgroup's echo table (k_us_bounce, k_us_shade).  Round 5: 256 -> 2048.  The table lives as long as the workgroup,
+// and a bin claimed by one channel index sends every other index that hashes there to the global atomic; 256 bins are enough while
+// a workgroup's first-bounce echoes land on <= n_elements words (the table-driven first bounce), but with CustomEmitter primary
+// rays (D15) every path has its own arrival time and 4096 first-bounce echoes spread over ~10^3 words that a hundred other
+// workgroups of the same ray hit too: bounce 0 took 1.62 ms per 16 Mi-path pass against 0.41 ms for bounce 1 with as many paths
+// (tools/us_per_depth.sh).  256 / 1024 / 2048 / 4096 bins: emitter rays 31.4 - 33.2 / 26.1 / 24.5 - 24.7 / 24.0 - 24.2 ms;
+// config 3 11.2 - 11.4 / 10.8 - 11.0 / 10.7 - 10.9 / 10.8 ms; the ring phantom 36.1 - 36.5 / 35.8 - 36.0 / 35.1 - 35.5 ms
+// (profiles/r05_us_echo_table_ab.txt).  A second, third, fourth bin tried before the global atomic (US_AGG_PROBES): flat.
+#ifndef US_AGG_LOG2
+#define US_AGG_LOG2 11
+#endif
 #define US_AGG_BINS (1u << US_AGG_LOG2)
+#ifndef US_AGG_PROBES
+#define US_AGG_PROBES 1
+#endif
 #ifndef US_WAVES_PER_EU
 #define US_WAVES_PER_EU 6
 #endif
@@ -390,9 +403,17 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
 #ifdef PBRT_ABLATE_US_AGG  // diagnostic builds only
                     atomicAdd(&a.channel[ci], pressure);
 #else
-                    const uint32_t bin = (ci * 2654435761u) >> (32 - US_AGG_LOG2);
-                    const uint32_t owner = atomicCAS(&agg_idx[bin], 0xffffffffu, ci);
-                    if (owner == 0xffffffffu || owner == ci)
+                    uint32_t bin = (ci * 2654435761u) >> (32 - US_AGG_LOG2);
+                    bool mine = false;
+#pragma unroll
+                    for (uint32_t pr = 0; pr < US_AGG_PROBES; ++pr) {  // (a bin owned by another index: the next one, US_AGG_PROBES tries)
+                        if (!mine) {
+                            const uint32_t owner = atomicCAS(&agg_idx[bin], 0xffffffffu, ci);
+                            mine = owner == 0xffffffffu || owner == ci;
+                            if (!mine) bin = (bin + 1u) & (US_AGG_BINS - 1u);
+                        }
+                    }
+                    if (mine)
                         __hip_atomic_fetch_add(&agg_sum[bin], pressure, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     else
                         atomicAdd(&a.channel[ci], pressure);

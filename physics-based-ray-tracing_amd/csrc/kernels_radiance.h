@@ -42,7 +42,13 @@
 #define REGION_SEGS_US 8
 #endif
 __host__ __device__ constexpr uint32_t rad_region_segs(int accel);
-__host__ __device__ constexpr uint32_t us_region_segs(int) { return REGION_SEGS_US; }
+// (emitter primary rays, D15: every first-bounce echo has its own arrival time, and the workgroup's echo table catches more of them
+// the more paths of a ray it sees before it is flushed -- 8 / 16 / 32 segments: 24.5 - 25.8 / 21.0 - 21.5 / 20.9 - 21.5 ms; with the
+// integrator's own rays, whose first bounce is table-driven, 16 segments cost 2 - 4 %: 10.8 - 10.9 -> 11.0 - 11.2 ms)
+#ifndef REGION_SEGS_US_EMIT
+#define REGION_SEGS_US_EMIT 16
+#endif
+__host__ __device__ constexpr uint32_t us_region_segs(int, bool emit = false) { return emit ? REGION_SEGS_US_EMIT : REGION_SEGS_US; }
 #define N_STATE 15
 #define MAX_DEPTH_STATS 62
 #define MAX_CHAIN 6  // bounces one launch of the multi-bounce kernels walks at most (the per-bounce counts are packed 10 bits each)

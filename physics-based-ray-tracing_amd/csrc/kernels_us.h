@@ -145,6 +145,9 @@ DEV uint32_t us_state_voff(uint32_t slot, uint32_t rows = US_N_STATE) { return (
 #define US_AGG_LOG2 11
 #endif
 #define US_AGG_BINS (1u << US_AGG_LOG2)
+#ifndef US_AGG_LOG2_EMIT
+#define US_AGG_LOG2_EMIT 12   // the EMIT instances of k_us_bounce (16-segment regions: 21.0 - 21.5 -> 20.5 ms)
+#endif
 #ifndef US_AGG_PROBES
 #define US_AGG_PROBES 1
 #endif
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn_lds[];
     __shared__ uint32_t wave_tot[2][SEG / 64];
     __shared__ uint32_t wave_seg[2][SEG / 64];
-    constexpr uint32_t REGION = us_region_segs(ACCEL) * SEG;
+    constexpr uint32_t REGION = us_region_segs(ACCEL, EMIT) * SEG;
     constexpr bool WP = rad_wave_private(ACCEL);  // BVH scenes: per-wave compaction, no barrier per chunk (see k_bounce)
     constexpr uint32_t W = SEG / 64, WREG = REGION / W, CH = WP ? 64u : SEG;
     const uint32_t seg = blockIdx.x, tid = threadIdx.x;  // seg: region index (see k_bounce)
@@ -213,9 +216,10 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     // float atomics on the same word serialise in L2 (measured: 64 % of the kernel).  Echoes are therefore summed
     // in a small LDS table keyed by the channel index (ds_cmpst claims a bin, ds_add_f32 adds); a bin owned by
     // another index falls back to the global atomic; one global atomic per used bin when the workgroup is done.
-    __shared__ uint32_t agg_idx[US_AGG_BINS];
-    __shared__ float agg_sum[US_AGG_BINS];
-    for (uint32_t t = threadIdx.x; t < US_AGG_BINS; t += blockDim.x) {
+    constexpr uint32_t AGG_LOG2 = EMIT ? US_AGG_LOG2_EMIT : US_AGG_LOG2, AGG_BINS = 1u << AGG_LOG2;
+    __shared__ uint32_t agg_idx[AGG_BINS];
+    __shared__ float agg_sum[AGG_BINS];
+    for (uint32_t t = threadIdx.x; t < AGG_BINS; t += blockDim.x) {
         agg_idx[t] = 0xffffffffu;
         agg_sum[t] = 0.0f;
     }
@@ -392,25 +396,33 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
                         // the echo's weight and carrier only where an echo is deposited: acosf and sinf are a tenth of the
                         // bounce, and e.g. every second bounce of the Sphere_Box phantom runs inside the sphere, unseen
                         float w_o = dot(d, si.ns) / (float)(a.p.n_angles * NE);        // :286-287,345 (si.sh_frame.n)
+#if defined(PBRT_ABLATE_US_DEPOSIT) && PBRT_ABLATE_US_DEPOSIT == 2
+                        fd = w_o;
+                        carrier = phase * 1e-9f;
+#else
                         fd = directivity_weight_i(sec_dir, tn, U_AM, U_AC) * w_o;      // :345
                         // f-3 pulse model: plain amplitude here, the carrier is applied by k_apply_pulse afterwards
                         carrier = (quirks & PBRT_USQ_NO_CARRIER) ? 1.0f : sinf(phase);
+#endif
                     }
                 }
                 float pressure = atten * amp * fd * carrier;                           // :348
+#ifdef PBRT_ABLATE_US_DEPOSIT  // timing probe only (wrong channel buffer): no echo is deposited; =2: the deposit stays, its weight is 1
+                if (PBRT_ABLATE_US_DEPOSIT == 1) ci = pressure != 12345.0f ? 0xffffffffu : ci;
+#endif
                 if (ci != 0xffffffffu) {
                     if (EMIT) pressure *= w_ray;  // the weight of the path's primary ray (DESIGN D15)
 #ifdef PBRT_ABLATE_US_AGG  // diagnostic builds only
                     atomicAdd(&a.channel[ci], pressure);
 #else
-                    uint32_t bin = (ci * 2654435761u) >> (32 - US_AGG_LOG2);
+                    uint32_t bin = (ci * 2654435761u) >> (32 - AGG_LOG2);
                     bool mine = false;
 #pragma unroll
                     for (uint32_t pr = 0; pr < US_AGG_PROBES; ++pr) {  // (a bin owned by another index: the next one, US_AGG_PROBES tries)
                         if (!mine) {
                             const uint32_t owner = atomicCAS(&agg_idx[bin], 0xffffffffu, ci);
                             mine = owner == 0xffffffffu || owner == ci;
-                            if (!mine) bin = (bin + 1u) & (US_AGG_BINS - 1u);
+                            if (!mine) bin = (bin + 1u) & (AGG_BINS - 1u);
                         }
                     }
                     if (mine)
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     ++depth;
     }  // bounce loop
     __syncthreads();  // all echoes of the workgroup are in the bins
-    for (uint32_t t = tid; t < US_AGG_BINS; t += SEG) {
+    for (uint32_t t = tid; t < AGG_BINS; t += SEG) {
         const uint32_t ci = agg_idx[t];
         if (ci != 0xffffffffu) atomicAdd(&a.channel[ci], agg_sum[t]);
     }

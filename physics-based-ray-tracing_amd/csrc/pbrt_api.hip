@@ -1975,7 +1975,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     // hipMalloc): a failed allocation gives the pass buffers back, halves the pass and tries again, like render_impl; the
     // echoes do not depend on the pass size (global path keys).  What did fit is released when even the smallest pass does not.
     const uint64_t US_MIN_PASS = 1u << 20;
-    const uint32_t REGION = streams ? WF_REGION : us_region_segs(s->accel_kernel) * seg_threads(s->accel_kernel);
+    const uint32_t REGION = streams ? WF_REGION : us_region_segs(s->accel_kernel, emit) * seg_threads(s->accel_kernel);
     uint32_t ppr_pass = 1, cap = 0, nseg = 0;
     WfBufs wfb{};
     WfPlan wfp;

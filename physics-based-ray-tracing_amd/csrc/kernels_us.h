@@ -31,6 +31,7 @@ struct UsArgs {
     uint32_t lds_bytes;
     uint32_t stat_stride;
     uint32_t fuse;  // bounces a.depth .. max_depth - 1 in this launch (k_us_bounce<false>)
+    uint32_t blk_mul;  // 0: workgroup b walks region b; else region (b * blk_mul) mod gridDim.x (coprime: a permutation) -- emitter rays
     FastDiv div_ppr, div_ne;  // exact home / ppr_pass and ray_id / n_elements without the 20-instruction variable udiv
     // First-bounce tables (k_us_first): the primary ray of an (angle, element) pair is deterministic
     // (CustomIntegrator.py:270-273), so all P paths of a ray share the first hit, and the occlusion of the ray to a
@@ -186,7 +187,12 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
     constexpr uint32_t REGION = us_region_segs(ACCEL, EMIT) * SEG;
     constexpr bool WP = rad_wave_private(ACCEL);  // BVH scenes: per-wave compaction, no barrier per chunk (see k_bounce)
     constexpr uint32_t W = SEG / 64, WREG = REGION / W, CH = WP ? 64u : SEG;
-    const uint32_t seg = blockIdx.x, tid = threadIdx.x;  // seg: region index (see k_bounce)
+    // seg: region index (see k_bounce).  Emitter rays: consecutive workgroups take regions a stride apart, so that the workgroups that
+    // run -- and flush their echo tables -- side by side do not belong to the same ray (the six regions of a ray's paths land on the
+    // same ~10^3 channel words): 20.3 -> 18.4 ms.  Any stride of a ray or more does (7 .. 1229 of 2048 regions: 18.5 - 19.0 ms); the
+    // host takes regions / n_angles.  With the integrator's own rays (table-driven first bounce, <= 64 words per ray) it changes nothing
+    const uint32_t seg = a.blk_mul ? (uint32_t)(((unsigned long long)blockIdx.x * a.blk_mul) % gridDim.x) : blockIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t lane_c = WP ? (tid & 63u) : tid;
     const uint32_t own = WP ? seg * W + (tid >> 6) : seg;
     const uint32_t base = WP ? seg * REGION + (tid >> 6) * WREG : seg * REGION;

@@ -445,6 +445,12 @@ class DeviceBuffer:
             raise ValueError(f"upload of {a.nbytes} bytes into a buffer of {self.nbytes}")
         self.ctx.check(self.ctx.lib.pbrt_dev_upload(self.ctx.handle, _P(self.ptr), addr(a), C.c_uint64(self.nbytes)), "pbrt_dev_upload")
 
+    @property
+    def __cuda_array_interface__(self) -> dict:
+        """zero-copy hand-over to a GPU array library of the same process (`torch.as_tensor(buf, device="cuda")`, CuPy): the
+        consumer must order its work behind the context's stream itself (Context.synchronize(), or a stream wait)"""
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 2, "strides": None}
+
     def numpy(self) -> np.ndarray:
         """copy to the host (waits for the queued work)"""
         out = np.empty(self.shape, self.dtype)

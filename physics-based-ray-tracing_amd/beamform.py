@@ -255,7 +255,8 @@ class _RenderPlan:
 
 
 def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range=60.0, step=None, seed=None,
-              paths_per_ray=None, beamformer=None, device_resident=True, return_bmode=True, timing=None, graph=True):
+              paths_per_ray=None, beamformer=None, device_resident=True, return_bmode=True, timing=None, graph=True,
+              on_device=False):
     """The reference's us_render (USMain.py:93-224) without the plotting: acquisition -> DAS -> envelope -> log
     compression.  Returns (display_image [nz, nx] in [0, 1], bmode envelope [nx, nz] (None with return_bmode=False),
     (x_scan, z_scan)).
@@ -267,7 +268,12 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
     A/B and the bit-for-bit test.  timing: a dict that receives host wall-clock seconds (acquire, queue, wait_copy).
     graph (default): from the third call in a row with the same arguments on, the queued calls are replayed from a recording
     (pbrt_ctx_record_begin / pbrt_graph_launch: one submission instead of eleven; same kernels, same bits); graph=False, or a
-    context that profiles (Context.set_profiling), queues them one by one."""
+    context that profiles (Context.set_profiling), queues them one by one.
+    on_device: nothing is copied and nothing waits -- the display image and the envelope come back as DeviceBuffers [nx, nz] (the
+    reference's display image is their transpose), still being written by the queued kernels; a caller that keeps its loss on
+    the GPU (USMain.py:5 imports torch: `torch.as_tensor(buf, device="cuda")` through __cuda_array_interface__) calls
+    scene.device().ctx.synchronize() before it reads them.  The buffers belong to the integrator's render plan: the next
+    us_render with the same scan overwrites them."""
     import time as _time
     integ = scene.integrator()
     A, E, T = integ.n_angles, integ.n_elements, integ.time_samples
@@ -372,6 +378,10 @@ def us_render(scene, x_range=(-0.04, 0.04), z_range=(0.001, 0.05), dynamic_range
     integ._set_device_channel(rf)
     d_env, d_img = plan.d_env, plan.d_img
     t2 = _time.perf_counter()
+    if on_device:
+        if timing is not None:
+            timing.update(acquire=t1 - t0, queue=t2 - t1, wait_copy=0.0, replayed=replayed)
+        return d_img, (d_env if return_bmode else None), (x_scan, z_scan)
     display = d_img.numpy().T                                                                          # :221  (the one copy)
     bmode = d_env.numpy() if return_bmode else None
     t3 = _time.perf_counter()

@@ -413,3 +413,22 @@ def test_us_render_replays_its_chain_from_the_third_call_on(mi):
     das_ms = cx.image_stats()["das_ms"]
     cx.set_profiling(False)
     assert not tm["replayed"] and das_ms > 0
+
+
+def test_us_render_hands_its_images_over_on_the_device(mi):
+    """on_device=True: the display image and the envelope as DeviceBuffers, nothing copied, nothing waited for; torch reads them
+    through __cuda_array_interface__ after a synchronise -- the same values as the host arrays of the plain call"""
+    import torch
+    sc = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=8, seed=2)
+    kw = dict(x_range=(-0.012, 0.012), z_range=(0.03, 0.07))
+    disp, env, (xs, zs) = mi.us_render(sc, **kw)
+    for _ in range(3):                                          # (the third call replays the recording)
+        d_img, d_env, _ = mi.us_render(sc, on_device=True, **kw)
+    assert isinstance(d_img, mi.DeviceBuffer) and d_img.shape == (len(xs), len(zs)) == d_env.shape
+    sc.device().ctx.synchronize()
+    t_img = torch.as_tensor(d_img, device="cuda")
+    t_env = torch.as_tensor(d_env, device="cuda")
+    assert t_img.data_ptr() == d_img.ptr and t_img.dtype == torch.float32 and tuple(t_img.shape) == d_img.shape
+    assert np.allclose(t_img.T.cpu().numpy(), disp, rtol=0, atol=1e-3) and np.allclose(t_env.cpu().numpy(), env, rtol=0, atol=2e-5 * env.max())
+    loss = torch.mean((t_img - torch.as_tensor(disp.T.copy(), device="cuda")) ** 2).item()   # a loss that never leaves the GPU
+    assert 0.0 <= loss < 1e-6

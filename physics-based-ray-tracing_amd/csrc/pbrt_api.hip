@@ -82,6 +82,7 @@ struct pbrt_ctx {
     // call that finds the same buffer and this flag set skips the fill command
     const void *us_rows_clean = nullptr;
     size_t us_rows_clean_bytes = 0;
+    uint64_t us_rows_epoch = 0;  // ws_epoch when the rows were left clean: a buffer freed since may have come back at the same address
     // the small tables of the last acquisition (transmit delays, primary directions, element positions) as uploaded: the
     // reference's loop calls the acquisition 51 times with the same ones (USMain.py:260,279-283), three host-to-device copies each
     std::vector<float> us_tab_host;
@@ -2045,7 +2046,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipMemsetAsync(d_channel, 0, nchan * 4, st));
     // (the rows are clean if the last acquisition's reduction has swept exactly this buffer; anything else -- a fresh or resized buffer,
     // a call that failed half-way -- gets the fill)
-    if (c->us_rows_clean != (const void *)dstats || c->us_rows_clean_bytes != segstats_bytes) {
+    if (c->us_rows_clean != (const void *)dstats || c->us_rows_clean_bytes != segstats_bytes || c->us_rows_epoch != c->ws_epoch) {
         if (c->recording) return c->fail(PBRT_E_INVALID, "recording: the acquisition's counters are not clean yet -- run the chain once before recording it");
         HIPCHK(c, hipMemsetAsync(dstats, 0, segstats_bytes, st));
     }
@@ -2172,6 +2173,7 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     HIPCHK(c, hipGetLastError());
     c->us_rows_clean = dstats;
     c->us_rows_clean_bytes = segstats_bytes;
+    c->us_rows_epoch = c->ws_epoch;
     if (streams && (rc = wf_guard_fetch(c, c->pin_guard())) != 0) return rc;
     pbrt_ctx::PendingAcq &P = c->pend;
     P.active = true;

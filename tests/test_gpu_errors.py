@@ -201,3 +201,29 @@ def test_a_failed_allocation_halves_the_pass_of_an_acquisition(mi, monkeypatch):
     finally:
         monkeypatch.delenv("PBRT_DEBUG_ALLOC_FAIL_BYTES", raising=False)
         ctx.set_workspace_limit(0)
+
+
+def test_acquisition_counters_survive_what_happens_between_two_acquisitions(mi):
+    """the counter rows are zeroed by the reduction of the acquisition before (no fill command per call): a render, a trim that
+    hands the rows back, a freed device buffer or another scene in between must not leave stale or uninitialised counters"""
+    ctx = mi.default_context()
+    us = mi.load_file(scene_path("us_plate.xml"), paths_per_ray=64, seed=4)
+    ui = us.integrator()
+    ui.simulate_acquisition_parallel(us)
+    ref = ctx.stats()
+    assert ref["samples"] == 5 * 64 * 64 and ref["segments"] > 0
+    for between in ("nothing", "render", "trim", "dev_free", "other_acquisition"):
+        if between == "render":
+            mi.render(mi.load_file(scene_path("cbox.xml"), res=32, spp=4), seed=1)
+        elif between == "trim":
+            mi.render(mi.load_file(scene_path("cbox.xml"), res=32, spp=4), seed=1)
+            ctx.trim()                                        # the acquisition's buffers were not used by the last call: they go
+        elif between == "dev_free":
+            mi.DeviceBuffer(ctx, (1024,)).close()
+        elif between == "other_acquisition":
+            other = mi.load_file(scene_path("us_sphere_box.xml"), paths_per_ray=256, seed=1)
+            other.integrator().simulate_acquisition_parallel(other)
+            assert ctx.stats()["samples"] == 5 * 64 * 256
+        ui.simulate_acquisition_parallel(us)
+        st = ctx.stats()
+        assert (st["samples"], st["segments"], st["shadow_rays"], st["live"]) == (ref["samples"], ref["segments"], ref["shadow_rays"], ref["live"]), between

@@ -2106,8 +2106,8 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
         a.n_paths = n_rays * kc;
         const uint32_t nseg_pass = div_up(a.n_paths, REGION);
         a.blk_mul = 0;
-        static const char *e_perm = getenv("PBRT_US_EMIT_PERMUTE");  // A/B: 0 keeps workgroup b on region b
-        static const char *e_perm_all = getenv("PBRT_US_PERMUTE_ALL");  // A/B: the integrator's own rays as well
+        const char *e_perm = getenv("PBRT_US_EMIT_PERMUTE");  // A/B and test: 0 keeps workgroup b on region b (read per call)
+        const char *e_perm_all = getenv("PBRT_US_PERMUTE_ALL");  // A/B: the integrator's own rays as well
         if ((emit || (e_perm_all && atoi(e_perm_all) != 0)) && !streams && nseg_pass > 2u * NA && !(e_perm && atoi(e_perm) == 0)) {
             uint32_t m = (nseg_pass / NA) | 1u;
             if (e_perm && atoi(e_perm) > 1) m = (uint32_t)atoi(e_perm) | 1u;  // (A/B: another stride)

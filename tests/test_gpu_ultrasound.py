@@ -380,3 +380,28 @@ def test_specialised_and_generic_bounce_kernels_agree(mi, capi, monkeypatch, sce
         monkeypatch.delenv("PBRT_US_GENERIC_KERNEL")
         assert st_fast["segments"] == st_gen["segments"] > 0 and st_fast["live"] == st_gen["live"]
         assert np.array_equal(fast != 0, gen != 0) and np.allclose(fast, gen, rtol=2e-5, atol=1e-7 * np.abs(gen).max())
+
+
+def test_emitter_rays_with_and_without_the_region_permutation(mi, ob, monkeypatch):
+    """PBRT_US_PRIMARY_EMITTER at a size where a pass has many regions (160 regions of 8192 paths): workgroup b walks region
+    (b * m) mod regions (a permutation; kernels_us.h) -- the same echoes as with workgroup b on region b (f32 atomics in another
+    order), the same counters, and the oracle's channel buffer at the acquisition's tolerance"""
+    sc = mi.load_file(scene_path("us_sphere_box.xml"), primary_rays="emitter", paths_per_ray=4096, seed=6)
+    ui = sc.integrator()
+    ctx = sc.device().ctx
+    a = ui._acquire(sc, ui.quirks)
+    st_a = ctx.stats()
+    monkeypatch.setenv("PBRT_US_EMIT_PERMUTE", "0")
+    b = ui._acquire(sc, ui.quirks)
+    st_b = ctx.stats()
+    monkeypatch.delenv("PBRT_US_EMIT_PERMUTE")
+    monkeypatch.setenv("PBRT_US_EMIT_PERMUTE", "7")                      # another stride
+    c = ui._acquire(sc, ui.quirks)
+    monkeypatch.delenv("PBRT_US_EMIT_PERMUTE")
+    assert (st_a["segments"], st_a["shadow_rays"], st_a["live"]) == (st_b["segments"], st_b["shadow_rays"], st_b["live"])
+    for x in (b, c):
+        assert np.array_equal(a != 0, x != 0) and np.allclose(a, x, rtol=0, atol=2e-5 * np.abs(a).max())
+    osc = ob.OracleScene.from_scene(sc)
+    ref, _ = osc.us_acquire(ui.us_params(sc), 6, 4096)
+    ref = np.asarray(ref).reshape(a.shape)
+    assert np.linalg.norm(a - ref) <= 1e-3 * np.linalg.norm(ref) and np.array_equal(a != 0, ref != 0)

@@ -2023,8 +2023,10 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
-    const char *e_fused = getenv("PBRT_US_EMIT_FUSED");  // A/B: draw the emitter ray inside the first-bounce kernel
-    const bool emit_fused = e_fused && atoi(e_fused) != 0;
+    // emitter rays are drawn inside the first-bounce instance (k_us_bounce<true, ., EMIT>); PBRT_US_EMIT_FUSED=0 (A/B, test) writes them
+    // into the path state first (k_us_emit_init) and walks every bounce with the later-bounce instance
+    const char *e_fused = getenv("PBRT_US_EMIT_FUSED");
+    const bool emit_fused = !(e_fused && atoi(e_fused) == 0);
     // the three small tables in one host image; uploaded only when they differ from what the device copy already holds
     {
         std::vector<float> img((size_t)n_rays + 3 * NA + NE);

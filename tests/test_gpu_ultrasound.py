@@ -398,8 +398,13 @@ def test_emitter_rays_with_and_without_the_region_permutation(mi, ob, monkeypatc
     monkeypatch.setenv("PBRT_US_EMIT_PERMUTE", "7")                      # another stride
     c = ui._acquire(sc, ui.quirks)
     monkeypatch.delenv("PBRT_US_EMIT_PERMUTE")
+    monkeypatch.setenv("PBRT_US_EMIT_FUSED", "0")                        # the rays through k_us_emit_init and the path state
+    e = ui._acquire(sc, ui.quirks)
+    st_e = ctx.stats()
+    monkeypatch.delenv("PBRT_US_EMIT_FUSED")
     assert (st_a["segments"], st_a["shadow_rays"], st_a["live"]) == (st_b["segments"], st_b["shadow_rays"], st_b["live"])
-    for x in (b, c):
+    assert (st_a["segments"], st_a["shadow_rays"], st_a["live"]) == (st_e["segments"], st_e["shadow_rays"], st_e["live"])
+    for x in (b, c, e):
         assert np.array_equal(a != 0, x != 0) and np.allclose(a, x, rtol=0, atol=2e-5 * np.abs(a).max())
     osc = ob.OracleScene.from_scene(sc)
     ref, _ = osc.us_acquire(ui.us_params(sc), 6, 4096)

@@ -236,10 +236,12 @@ def main():
         return out
     out = measure(env, name, cfg, steps, warmup, seed=0, overridden=overridden, with_cpu=(world == 1 and not args.no_cpu_baseline))
     if rank == 0 and world == 1 and args.config is None and not overridden and not args.no_also:
-        # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line
+        # the driver runs this command once: the other named scenes of BASELINE.json ride on the same line (three timed steps after
+        # TWO warm-up steps: after the CPU legs of the entry before, the first acquisition or two run ~10 % slow -- clocks,
+        # tools/idle_gap_probe.py)
         out["also"] = []
         for other in ("us_sphere_box", "us_sphere_box_emitter", "testring", "us_testring", "cbox4k"):
-            o = measure(env, other, dict(CONFIGS[other]), 3, 1, seed=0, overridden=False, with_cpu=not args.no_cpu_baseline,
+            o = measure(env, other, dict(CONFIGS[other]), 3, 2, seed=0, overridden=False, with_cpu=not args.no_cpu_baseline,
                         cpu_seconds=min(args.cpu_seconds, 6.0))
             keep = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "roofline", "l2_vs_cpu_ref", "cpu_baseline", "config")
                     if k in o}

@@ -372,12 +372,26 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
     for k in acc:
         acc[k] = 0
     mine["work"] = mine["coll"] = 0.0
+    # (Python's cyclic collector stays out of the timed steps: after the CPU legs of the entry before -- hundreds of MB of NumPy
+    # results -- a generation-2 pass landed inside one timed step of every other run, 40 - 60 ms of host time in a 18 ms step)
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
+    step_s = []
     for _ in range(steps):
+        t_s = time.perf_counter()
         result = step()
+        step_s.append(time.perf_counter() - t_s)
     barrier()
     dt = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
+    if os.environ.get("BENCH_DEBUG_STEPS"):  # where does a step's wall-clock go?  (stderr; not part of the line)
+        print(f"[bench] {name}: wall per step {[round(x * 1e3, 2) for x in step_s]} ms, kernel ms summed {acc['kernel_ms']:.2f}, "
+              f"rank work {mine['work'] * 1e3:.2f} ms, collective {mine['coll'] * 1e3:.2f} ms", file=sys.stderr, flush=True)
     per_rank = None
     if world > 1:
         cdev = "cpu" if args.rehearse_on_one_gpu else device

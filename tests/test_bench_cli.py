@@ -43,9 +43,8 @@ def test_tool_scripts_compile():
     """the measurement helpers under tools/ are run by hand on the GPU box: at least keep them parseable"""
     import glob
     import os
-    import py_compile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     scripts = sorted(glob.glob(os.path.join(root, "tools", "*.py")))
     assert len(scripts) >= 20
     for f in scripts:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        compile(open(f).read(), f, "exec")      # (syntax only: nothing is imported, nothing is written)
